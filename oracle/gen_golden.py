@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE on CPU in the build container.
+
+    python oracle/gen_golden.py            # needs /root/reference (read-only mount)
+
+The reference cannot travel to the GPU box, so what is committed is DATA only:
+seeded inputs (graph, weights keyed by the reference's state_dict names,
+literals, batches) and the outputs the reference's own model.py / model_bce.py /
+gate.py produced for them with torch CPU in this container.  No reference source
+text is written anywhere.  Re-running this script regenerates the same files
+(torch CPU RNG, fixed seeds).
+
+Fixture families:
+  attention_*  a4 per-edge logits + a5 refreshed A_in (indices int64 bit-exact, values)
+  encoder_*    a1/a2/a3/a6/a7 gat_embeddings for aggregator x residual x gate x scale combos,
+               a8 TransR loss, pos/neg scores, gradients of every trainable parameter
+  transe_*     a9 TransE loss (model_bce.py) + gradients
+  heads_*      f1 fine-tuning loss, calc_score matrix, predict_links
+  statedict    key -> shape manifest of the reference's state_dict
+"""
+import io
+import json
+import os
+import sys
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def ref_modules():
+    sys.path.insert(0, REF)
+    import model as ref_model          # noqa: E402
+    import model_bce as ref_model_bce  # noqa: E402
+    return ref_model, ref_model_bce
+
+
+def make_args(**over):
+    a = dict(use_pretrain=0, device="cpu", embed_dim=16, relation_dim=16, scale_gat_dim=None,
+             use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=1,
+             conv_dim=16, mess_dropout=0.0, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
+             pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=20,
+             use_num_lit=False, use_txt_lit=False, milestone_score=0.5, n_mlp_layers=2,
+             mlp_hidden_dim=12)
+    a.update(over)
+    return a
+
+
+def random_graph(rng, n, e, n_rel, n_dup_pairs):
+    """Distinct (h,r,t) triples, skewed heads, plus forced duplicate (h,t) pairs under a 2nd relation."""
+    h = (n * rng.random(e) ** 1.7).astype(np.int64)
+    t = rng.integers(0, n, e)
+    r = rng.integers(0, n_rel, e)
+    trip = np.unique(np.stack([h, r, t], 1), axis=0)
+    extra = trip[rng.choice(len(trip), n_dup_pairs, replace=False)].copy()
+    extra[:, 1] = (extra[:, 1] + 1 + rng.integers(0, n_rel - 1, n_dup_pairs)) % n_rel
+    trip = np.unique(np.concatenate([trip, extra]), axis=0)
+    trip = trip[rng.permutation(len(trip))]
+    return trip[:, 0].copy(), trip[:, 2].copy(), trip[:, 1].copy()
+
+
+def laplacian(n, h, t, r):
+    """Same construction as the loader's random-walk sum over relations (own scipy code)."""
+    import scipy.sparse as sp
+    acc = None
+    for rid in sorted(set(r.tolist())):
+        m = r == rid
+        adj = sp.coo_matrix((np.ones(m.sum()), (h[m], t[m])), shape=(n, n)).tocsr()
+        deg = np.asarray(adj.sum(axis=1)).ravel()
+        inv = np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0)
+        lap = sp.diags(inv) @ adj
+        acc = lap if acc is None else acc + lap
+    acc = acc.tocoo()
+    idx = torch.from_numpy(np.vstack([acc.row, acc.col]).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(acc.data.astype(np.float32)), (n, n)).coalesce()
+
+
+def sd_to_np(sd):
+    return {"p/" + k: v.detach().cpu().numpy() for k, v in sd.items() if k != "A_in"}
+
+
+def build(cls, args, n, n_rel, a_in, num, txt, seed):
+    torch.manual_seed(seed)
+    m = cls(SimpleNamespace(**args), n, n_rel, a_in, num, txt)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if "gate_bias" in name or name.endswith(".bias"):
+                prm.add_(0.05 * torch.randn_like(prm))   # make biases non-trivial
+        if args["aggregation_type"] == "gin":
+            # Aggregator.weight of 'gin' is re-allocated uninitialised (model.py:61): pin it
+            for k in range(args["n_conv_layers"]):
+                m.aggregator_layers[k].weight.uniform_(-0.25, 0.25)
+    m.eval()
+    return m
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def attention_case(ref_model, name, n, h, t, r, dim, seed):
+    n_rel = int(r.max()) + 1
+    args = make_args(embed_dim=dim, relation_dim=dim, conv_dim=dim)
+    m = build(ref_model.LiteralKG, args, n, n_rel, None, None, None, seed)
+    ht, tt, rt = (torch.from_numpy(x) for x in (h, t, r))
+    logits = np.zeros(len(h), np.float32)
+    with torch.no_grad():
+        for rid in range(n_rel):
+            sel = np.nonzero(r == rid)[0]
+            if len(sel):
+                logits[sel] = m.update_attention_batch(ht[sel], tt[sel], rid).numpy()
+        m(ht, tt, rt, list(range(n_rel)), device=torch.device("cpu"), mode="update_att")
+    a = m.A_in.data.coalesce()
+    save(name, n=np.int64(n), h=h, t=t, r=r,
+         entity=m.entity_embed.weight.detach().numpy(), relation=m.relation_embed.weight.detach().numpy(),
+         logits=logits, a_indices=a.indices().numpy(), a_values=a.values().numpy())
+
+
+def encoder_case(cls, name, args, n, h, t, r, seed, form, rng):
+    n_rel = int(r.max()) + 1
+    a_in = laplacian(n, h, t, r)
+    num = torch.from_numpy(rng.random((n, args["num_lit_dim"])).astype(np.float32)) if args["use_num_lit"] else None
+    txt = torch.from_numpy(rng.standard_normal((n, args["txt_lit_dim"])).astype(np.float32)) if args["use_txt_lit"] else None
+    m = build(cls, args, n, n_rel, a_in, num, txt, seed)
+    k = args["pre_training_neg_rate"]
+    groups = 40
+    bh = np.repeat(rng.integers(0, n, groups), k)
+    br = np.repeat(rng.integers(0, n_rel, groups), k)
+    bp = np.repeat(rng.integers(0, n, groups), k)
+    bn = rng.integers(0, n, groups * k)
+    tb = [torch.from_numpy(x) for x in (bh, br, bp, bn)]
+    dev = torch.device("cpu")
+    loss = m(*tb, device=dev, mode="pre_training")
+    loss.backward()
+    grads = {"g/" + k_: v.grad.detach().numpy() for k_, v in m.named_parameters()
+             if v.grad is not None and k_ != "A_in"}
+    with torch.no_grad():
+        gat = m.gat_embeddings()
+        hd, rl = gat[tb[0]], m.relation_embed(tb[1])
+        if form == "transr":
+            w = m.gat_trans_M[tb[1]]
+            pr = lambda x: torch.bmm(x.unsqueeze(1), w).squeeze(1)  # noqa: E731
+            ph, pp, pn = pr(hd), pr(gat[tb[2]]), pr(gat[tb[3]])
+        else:
+            ph, pp, pn = hd, gat[tb[2]], gat[tb[3]]
+        pos = ((ph + rl - pp) ** 2).sum(1).numpy()
+        neg = ((ph + rl - pn) ** 2).sum(1).numpy()
+    arrs = dict(cfg=np.array(json.dumps(args)), form=np.array(form), n=np.int64(n), n_rel=np.int64(n_rel),
+                h=h, t=t, r=r, a_indices=a_in.indices().numpy(), a_values=a_in.values().numpy(),
+                bh=bh, br=br, bp=bp, bn=bn, gat=gat.numpy(), loss=loss.detach().numpy(),
+                pos=pos, neg=neg)
+    if num is not None:
+        arrs["num"] = num.numpy()
+    if txt is not None:
+        arrs["txt"] = txt.numpy()
+    arrs.update(sd_to_np(m.state_dict()))
+    arrs.update(grads)
+    if form == "transr":
+        # f1 heads ride on the same encoder
+        hid = torch.from_numpy(rng.integers(0, n, 9))
+        tid = torch.from_numpy(rng.integers(0, n, 11))
+        with torch.no_grad():
+            arrs["score_heads"], arrs["score_tails"] = hid.numpy(), tid.numpy()
+            arrs["score"] = m.calc_score(hid, tid).numpy()
+            arrs["predict"] = m(hid, tid, device=dev, mode="predict").numpy()
+        m.zero_grad()
+        ft = m(tb[0], tb[2], tb[3], device=dev, mode="fine_tuning")
+        ft.backward()
+        arrs["ft_loss"] = ft.detach().numpy()
+        arrs["ft_g/entity_embed.weight"] = m.entity_embed.weight.grad.numpy()
+    save(name, **arrs)
+    return m
+
+
+def main():
+    ref_model, ref_model_bce = ref_modules()
+    rng = np.random.default_rng(2022)
+
+    # ---- attention ------------------------------------------------------
+    # 5-node toy with a duplicate (h,t) pair under two relations
+    h = np.array([0, 0, 0, 1, 2, 2, 4], np.int64)
+    t = np.array([1, 1, 2, 3, 0, 4, 4], np.int64)
+    r = np.array([0, 1, 0, 1, 0, 1, 0], np.int64)
+    attention_case(ref_model, "attention_toy5", 5, h, t, r, 8, 1)
+    hh, tt, rr = random_graph(rng, 300, 2400, 5, 12)
+    attention_case(ref_model, "attention_rand300", 300, hh, tt, rr, 32, 2)
+    # slice of the reference's shipped KG file, chosen to contain its duplicate (h,t) pairs
+    trip = np.loadtxt(os.path.join(REF, "data/Test/pre_training_train.txt"), dtype=np.int64)
+    key = trip[:, 0] * (trip.max() + 1) + trip[:, 2]
+    uk, cnt = np.unique(key, return_counts=True)
+    dup_heads = np.unique(uk[cnt > 1] // (trip.max() + 1))[:12]
+    sel = np.isin(trip[:, 0], dup_heads)
+    sel[:1500] = True
+    sub = trip[sel][:2000]
+    ents, inv = np.unique(np.concatenate([sub[:, 0], sub[:, 2]]), return_inverse=True)
+    sh, st = inv[:len(sub)].astype(np.int64), inv[len(sub):].astype(np.int64)
+    attention_case(ref_model, "attention_testslice", len(ents), sh, st, sub[:, 1].copy(), 16, 3)
+
+    # ---- encoder + TransR ----------------------------------------------
+    n = 240
+    gh, gt, gr = random_graph(rng, n, 1500, 4, 8)
+    combos = [
+        ("gcn_l1", dict()),
+        ("gcn_l2_scale", dict(n_conv_layers=2, scale_gat_dim=24)),
+        ("gcn_l2_res_wide", dict(n_conv_layers=2, use_residual=True, conv_dim=16)),
+        ("gcn_l1_conv8", dict(conv_dim=8)),
+        ("sage_l2", dict(aggregation_type="graphsage", n_conv_layers=2, conv_dim=12)),
+        ("sage_l1_res", dict(aggregation_type="graphsage", use_residual=True)),
+        ("bi_l2", dict(aggregation_type="bi-interaction", n_conv_layers=2)),
+        ("bi_l1_res", dict(aggregation_type="bi-interaction", use_residual=True)),
+        ("gin_l2", dict(aggregation_type="gin", n_conv_layers=2)),
+        ("gin_l1_res", dict(aggregation_type="gin", use_residual=True)),
+        ("gcn_l1_gatemul", dict(use_num_lit=True, use_txt_lit=True)),
+        ("gcn_l2_gatenum", dict(use_num_lit=True, n_conv_layers=2)),
+        ("gcn_l1_gatetxt_scale", dict(use_txt_lit=True, scale_gat_dim=16)),
+    ]
+    manifest = {}
+    for i, (nm, over) in enumerate(combos):
+        m = encoder_case(ref_model.LiteralKG, "encoder_" + nm, make_args(**over), n, gh, gt, gr, 10 + i,
+                         "transr", rng)
+        manifest[nm] = {k: list(v.shape) for k, v in m.state_dict().items()}
+
+    # ---- TransE (model_bce) --------------------------------------------
+    for i, (nm, over) in enumerate([
+        ("gcn_l1", dict(scale_gat_dim=16)),
+        ("gcn_l2_gatemul", dict(scale_gat_dim=16, n_conv_layers=2, use_num_lit=True, use_txt_lit=True)),
+    ]):
+        encoder_case(ref_model_bce.LiteralKG, "transe_" + nm, make_args(**over), n, gh, gt, gr, 40 + i,
+                     "transe", rng)
+
+    with open(os.path.join(OUT, "statedict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

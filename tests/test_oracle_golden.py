@@ -1,0 +1,96 @@
+"""CPU: the oracle (oracle/literalkg_oracle.py) against the fixtures produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, golden_names, golden_params, load_golden
+from oracle import literalkg_oracle as O
+
+TOL = 1e-5   # oracle and reference run the same ATen ops on the same CPU: near bit-equal
+
+
+def _a_in(g):
+    n = int(g["n"])
+    return torch.sparse_coo_tensor(torch.from_numpy(g["a_indices"]), torch.from_numpy(g["a_values"]), (n, n)).coalesce()
+
+
+@pytest.mark.parametrize("name", golden_names("attention_"))
+def test_attention(name):
+    g = load_golden(name)
+    n = int(g["n"])
+    ent, rel = torch.from_numpy(g["entity"]), torch.from_numpy(g["relation"])
+    h, t, r = (torch.from_numpy(g[k]) for k in "htr")
+    np.testing.assert_allclose(O.edge_logits(ent, rel, h, t, r).numpy(), g["logits"], rtol=TOL, atol=TOL)
+    a = O.attention_refresh(n, ent, rel, h, t, r).coalesce()
+    assert np.array_equal(a.indices().numpy(), g["a_indices"])          # bit-exact int64 indices
+    np.testing.assert_allclose(a.values().numpy(), g["a_values"], rtol=TOL, atol=1e-7)
+    rows, cols, vals = O.attention_refresh_explicit(n, ent, rel, h, t, r)
+    assert np.array_equal(torch.stack([rows, cols]).numpy(), g["a_indices"])
+    np.testing.assert_allclose(vals.numpy(), g["a_values"], rtol=1e-5, atol=1e-7)
+    # rows of the refreshed matrix sum to one, duplicate pairs are merged
+    rs = np.zeros(n)
+    np.add.at(rs, g["a_indices"][0], g["a_values"])
+    assert np.allclose(rs[np.unique(g["a_indices"][0])], 1.0, atol=1e-5)
+    assert g["a_indices"].shape[1] <= len(g["h"])
+
+
+@pytest.mark.parametrize("name", golden_names("encoder_") + golden_names("transe_"))
+def test_encoder_loss_grads(name):
+    g = load_golden(name)
+    cfg, form = golden_cfg(g), str(g["form"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in golden_params(g).items()}
+    a = _a_in(g)
+    num = torch.from_numpy(g["num"]) if "num" in g else None
+    txt = torch.from_numpy(g["txt"]) if "txt" in g else None
+    bh, br, bp, bn = (torch.from_numpy(g[k]) for k in ("bh", "br", "bp", "bn"))
+    gat = O.gat_embeddings(p, cfg, a, num, txt)
+    np.testing.assert_allclose(gat.detach().numpy(), g["gat"], rtol=TOL, atol=TOL)
+    if form == "transr":
+        pos, neg, _ = O.triple_scores_transr(p, gat, bh, br, bp, bn)
+        loss = O.triple_loss_transr(p, cfg, gat, bh, br, bp, bn)
+    else:
+        pos, neg, _ = O.triple_scores_transe(p, gat, bh, br, bp, bn)
+        loss = O.triple_loss_transe(p, cfg, gat, bh, br, bp, bn)
+    np.testing.assert_allclose(pos.detach().numpy(), g["pos"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(neg.detach().numpy(), g["neg"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=TOL)
+    loss.backward()
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("g/"):
+            got = p[k[2:]].grad
+            assert got is not None, k
+            np.testing.assert_allclose(got.numpy(), v, rtol=1e-4, atol=1e-7, err_msg=k)
+            checked += 1
+    assert checked >= 4
+    # parameters the reference left without a gradient stay without one here too
+    for k, v in p.items():
+        if "g/" + k not in g:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("name", golden_names("encoder_"))
+def test_heads(name):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in golden_params(g).items()}
+    num = torch.from_numpy(g["num"]) if "num" in g else None
+    txt = torch.from_numpy(g["txt"]) if "txt" in g else None
+    gat = O.gat_embeddings(p, cfg, _a_in(g), num, txt)
+    hid, tid = torch.from_numpy(g["score_heads"]), torch.from_numpy(g["score_tails"])
+    np.testing.assert_allclose(O.link_scores(gat, hid, tid).detach().numpy(), g["score"], rtol=TOL, atol=TOL)
+    assert np.array_equal(O.predict_links(cfg, gat.detach(), hid, tid).numpy(), g["predict"])
+    bh, bp, bn = (torch.from_numpy(g[k]) for k in ("bh", "bp", "bn"))
+    ft = O.prediction_loss(cfg, gat, bh, bp, bn)
+    np.testing.assert_allclose(ft.item(), g["ft_loss"], rtol=TOL)
+    ft.backward()
+    np.testing.assert_allclose(p["entity_embed.weight"].grad.numpy(), g["ft_g/entity_embed.weight"],
+                               rtol=1e-4, atol=1e-7)
+
+
+def test_laplacian_matches_fixture_inputs():
+    g = load_golden("encoder_gcn_l1")
+    h, t, r = (torch.from_numpy(g[k]) for k in "htr")
+    a = O.laplacian_a_in(int(g["n"]), h, t, r)
+    assert np.array_equal(a.indices().numpy(), g["a_indices"])
+    np.testing.assert_allclose(a.values().numpy(), g["a_values"], rtol=1e-6)
