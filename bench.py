@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- LiteralKG aggregation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): KG edges aggregated / s, 1 GAT layer, dim 256, plus % of the 8 TB/s HBM roofline.
+A STEP is one pass of the aggregation layer's sparse hot path over the whole graph:
+    forward   side      = A_in   @ ego        (lkg_spmm_csr_f32 on the CSR,  model.py:106)
+    backward  grad_ego  = A_in^T @ grad_side  (the same kernel on the CSC,   autograd of model.py:106)
+    N > 1     + the sum of the partial entity-gradient tables over ranks (RCCL all-reduce over xGMI)
+A_in holds a real refreshed attention (edge logits + row softmax from the fused K1+K2 kernel).
+`value` counts one aggregation per edge per pass: 2 * E edge-aggregations per step / wall time.
+Workload at N = 1: synthetic KG 1M entities / 10M edges, D = 256 (the config the metric is quoted on);
+at N > 1 every rank owns a head-row range of 625k entities / 12.5M edges (N = 8 is BASELINE config[3]:
+5M entities / 100M edges) and holds a full replica of the source table (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(nnz, n_out_rows, d):
+    """one D-row gather + int32 col + fp32 value per stored entry, one output row per
+    destination, the row pointer array."""
+    return nnz * (4 * d + 8) + n_out_rows * 4 * d + 4 * (n_out_rows + 1)
+
+
+def cpu_baseline(g, val, n, d, seed):
+    """The oracle (the ATen ops the reference dispatches: sparse COO matmul forward, its autograd
+    transpose product backward) timed on this box's host cores on the SAME graph and attention values:
+    1 forward + 1 backward pass."""
+    from oracle import literalkg_oracle as O
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(seed)
+    bound = (6.0 / (n + d)) ** 0.5
+    ent = (torch.rand((n, d), generator=gen) * 2 - 1) * bound
+    rp = g.host("rowptr")
+    idx = torch.from_numpy(np.stack([np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)),
+                                     g.host("col").astype(np.int64)]))
+    a = torch.sparse_coo_tensor(idx, val.cpu(), (n, n), is_coalesced=True)
+    x = ent.clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    side = O.aggregate(a, x)
+    t1 = time.perf_counter()
+    side.backward(torch.ones_like(side))
+    t2 = time.perf_counter()
+    edges = 2 * a._nnz()
+    return {"value": edges / (t2 - t0), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward ({t1 - t0:.2f} s) + 1 backward ({t2 - t1:.2f} s) torch-CPU sparse matmul pass over the "
+                      f"same graph ({a._nnz()} stored entries, D={d}), torch {torch.__version__}, "
+                      f"{cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--entities", type=int, default=None, help="per-GPU entities (default 1M at N=1, 625k at N>1)")
+    ap.add_argument("--edges", type=int, default=None, help="per-GPU edges (default 10M at N=1, 12.5M at N>1)")
+    ap.add_argument("--skew", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=4, help="tail-row chunks of the backward (comm overlap)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import literalkg_amd as L
+    from literalkg_amd import ops
+    from literalkg_amd.sharding import ShardedAggregation
+    from literalkg_amd.synth import make_kg, xavier_table
+
+    d = args.dim
+    n_loc = args.entities or (1_000_000 if world == 1 else 625_000)
+    e_loc = args.edges or (10_000_000 if world == 1 else 12_500_000)
+    n_glob = n_loc * world
+    lo, hi = rank * n_loc, (rank + 1) * n_loc
+
+    # this rank's head rows: heads drawn inside [lo, hi), tails over all entities
+    t0 = time.perf_counter()
+    if world == 1:
+        h, t, r = make_kg(n_glob, e_loc, args.skew, seed=2022)
+    else:
+        hl, _, r = make_kg(n_loc, e_loc, args.skew, seed=2022 + rank)
+        h = hl + lo
+        t = np.random.default_rng(4044 + rank).integers(0, n_glob, len(h), dtype=np.int64)
+    g = L.KGStructure.from_triples(n_glob, h, t, r, device=dev)
+    t_build = time.perf_counter() - t0
+
+    ent = xavier_table(n_glob, d, dev, seed=2022)              # same table on every rank (replica)
+    relemb = xavier_table(16, d, dev, seed=7)
+    val, _ = ops.edge_softmax(g, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
+    shard = ShardedAggregation(g, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
+    grad_side = torch.randn((hi - lo, d), device=dev)
+    side = torch.empty((hi - lo, d), device=dev)
+    grad_table = torch.empty((n_glob, d), device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        shard.forward(ent, out=side)
+        if ev is not None:
+            ev[1].record()
+        shard.backward(grad_side, out=grad_table)
+        if ev is not None:
+            ev[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    nnz_all = torch.tensor([g.nnz], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
+    elapsed = float(el)
+    total_entries = int(nnz_all)
+
+    # dominant kernel = the forward SpMM launch; HIP events on the launch stream (torch's current stream)
+    fwd_ms = np.array([ev[0].elapsed_time(ev[1]) for ev in events])
+    bwd_ms = np.array([ev[1].elapsed_time(ev[2]) for ev in events])
+    by = algorithmic_bytes(g.nnz, hi - lo, d)
+    achieved = by / (fwd_ms.mean() * 1e-3) / 1e9
+    by_bwd = algorithmic_bytes(g.nnz, n_glob, d)
+
+    if rank == 0:
+        out = {
+            "metric": "kg_edges_aggregated_per_sec",
+            "value": 2 * total_entries * args.steps / elapsed,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
+                            + (" + RCCL all-reduce of the entity-gradient table" if world > 1 else "")
+                            + f"; synthetic KG {n_glob} entities / {total_entries} stored (h,t) entries "
+                              f"({e_loc * world} triples, R=16, {args.skew} heads)",
+                "entities": n_glob, "stored_entries": total_entries, "triples": e_loc * world, "dim": d,
+                "edge_aggregations_per_step": 2 * total_entries, "passes": ["spmm_csr_fwd", "spmm_csc_bwd"],
+                "sharding": f"head-row ranges x{world}" if world > 1 else "none", "skew": args.skew,
+                "host_graph_build_s": round(t_build, 2),
+            },
+            "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel (forward launch)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
+                         "bwd_launch_ms": float(bwd_ms.mean()),
+                         "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if world == 1 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g, val, n_glob, d, 2022)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

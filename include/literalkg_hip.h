@@ -1,0 +1,210 @@
+/*
+ * literalkg_hip.h -- C ABI of the MI355X (gfx950) LiteralKG hot-path library.
+ *
+ * The reference (NSLab-CUK/LiteralKG) is pure Python on PyTorch and has NO native
+ * boundary of its own.  Its "plugin API" for this path is the
+ * nn.Module surface LiteralKG.forward(*input, device=, mode=) (model.py:521-532);
+ * literalkg_amd/model.py mirrors that surface and binds the entry points below
+ * with ctypes.  Each entry point names the reference lines whose ATen call
+ * sequence it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only, no torch types; every device function takes
+ *     the hipStream_t to launch on (as void*) and is asynchronous on it;
+ *   - no allocation, no host sync inside device functions (graph-capturable);
+ *   - return 0 on success, a negative lkg_status otherwise; lkg_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - all floating point is fp32, entity/column ids in the KG structure are int32,
+ *     batch triple ids are int64 (the dtype the reference's DataLoader hands over);
+ *   - "ld*" arguments are row strides in ELEMENTS so that callers can address
+ *     column slices of a concatenated table without a copy.
+ */
+#ifndef LITERALKG_HIP_H
+#define LITERALKG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LKG_OK = 0,
+    LKG_ERR_INVALID_ARG = -1,
+    LKG_ERR_HIP = -2,
+    LKG_ERR_UNSUPPORTED = -3,
+    LKG_ERR_NOMEM = -4
+} lkg_status;
+
+/* library version: major*10000 + minor*100 + patch */
+int lkg_version(void);
+const char *lkg_last_error(void);
+
+/* ------------------------------------------------------------------ host --
+ * KG structure build.  Replaces the per-relation torch.where / cat / stack /
+ * sparse_coo_tensor / coalesce sequence of LiteralKG.update_attention
+ * (model.py:451-468) and the scipy COO assembly of DataLoader
+ * (dataloader.py:449-495): triples are sorted by (head, tail); duplicate
+ * (head, tail) pairs under different relations are merged into ONE stored
+ * entry (their logits are summed later, as coalesce() does).
+ *
+ * in : n_entities, n_edges, h/t/r int64[n_edges] (host; r may be NULL -> 0)
+ * out: rowptr int32[n_entities+1], col int32[<=n_edges] (tails, ascending per row),
+ *      eptr int32[<=n_edges+1] (entry j covers sorted raw edges eptr[j]..eptr[j+1]),
+ *      rel int32[n_edges] (relation of each sorted raw edge),
+ *      order int64[n_edges] (sorted raw edge k is input edge order[k]),
+ *      *nnz_out = number of stored entries.
+ * All out buffers are caller-allocated with the upper-bound sizes above.      */
+int lkg_csr_build(int64_t n_entities, int64_t n_edges, const int64_t *h, const int64_t *t,
+                  const int64_t *r, int32_t *rowptr, int32_t *col, int32_t *eptr, int32_t *rel,
+                  int64_t *order, int64_t *nnz_out);
+
+/* CSC of the same pattern, for the backward pass grad_ego = A^T grad_side
+ * (autograd of model.py:106).  t_rowptr int32[n_cols+1], t_col int32[nnz]
+ * (heads, ascending per tail), t_perm int32[nnz]: transposed entry k is CSR
+ * entry t_perm[k].                                                          */
+int lkg_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr,
+                      const int32_t *col, int32_t *t_rowptr, int32_t *t_col, int32_t *t_perm);
+
+/* Cut [0, n_rows) into n_parts contiguous row ranges balanced by stored entries
+ * (cuts only at row boundaries so a softmax row never straddles two GPUs,
+ * SURVEY.md 8e).  cuts int64[n_parts+1].                                     */
+int lkg_row_partition(int64_t n_rows, const int32_t *rowptr, int32_t n_parts, int64_t *cuts);
+
+/* ---------------------------------------------------------------- device --
+ * K3/K4  neighbour aggregation  out[i,:] = sum_{j in row i} val[j] * x[col[j],:]
+ * Replaces torch.matmul(A_in, ego) (model.py:106); called with the CSC arrays
+ * it is the backward A^T grad.  Rows without entries are written as zeros.
+ * rowptr is int32[n_rows+1] holding offsets into col/val; x has >= max(col)+1 rows. */
+int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                     const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
+                     void *stream);
+
+/* K1+K2  attention refresh, fused: per stored entry
+ *     v = sum over its raw edges e of  sum_d ent[t,d] * tanh(ent[h,d] + relemb[rel[e],d])
+ * then softmax of v over the stored entries of each head row.
+ * Replaces update_attention_batch + coalesce + torch.sparse.softmax(A.cpu(), dim=1)
+ * (model.py:430-471).  eptr may be NULL when no (h,t) pair is duplicated
+ * (then rel is indexed by entry).  logits_out (nullable) receives the merged
+ * pre-softmax logits, val_out the attention values, both float[nnz].
+ * row_offset: rowptr holds n_rows+1 offsets for head rows row_offset..row_offset+n_rows
+ * (a row-range shard of a larger graph; ent always holds the full table).      */
+int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
+                         const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                         const float *ent, int64_t ld_ent, const float *relemb, int64_t ld_rel,
+                         float *val_out, float *logits_out, void *stream);
+
+/* dst[i] = src[perm[i]]  (attention values into CSC order after a refresh)     */
+int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src, float *dst, void *stream);
+
+/* K8  TransE-form triple scoring (model_bce.py:329-368; same math baselines.py:33-61)
+ *   pos_b = |e_h + r - e_p|^2, neg_b = |e_h + r - e_n|^2,
+ *   reg_b = (|e_h|^2 + |r|^2 + |e_p|^2 + |e_n|^2)/2,  rank_b = -logsigmoid(neg_b - pos_b)
+ * emb is the N x dim entity-side table (stride ld_emb), relemb the relation table.
+ * Outputs are float[batch] each.                                               */
+int lkg_transe_score_fwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb,
+                             const float *relemb, int64_t ld_rel, const int64_t *h,
+                             const int64_t *r, const int64_t *pos_t, const int64_t *neg_t,
+                             float *pos, float *neg, float *reg, float *rank, void *stream);
+
+/* loss = mean(rank) + lambda * mean(reg); one float written to loss_out.
+ * Replaces torch.mean / _L2_loss_mean / add (model.py:8-9, 420-426).           */
+int lkg_loss_reduce_f32(int64_t batch, const float *rank, const float *reg, float lambda,
+                        float *loss_out, void *stream);
+
+/* Backward of the two calls above.  g_loss is a device pointer to the upstream
+ * scalar gradient.  Accumulates (atomic add) into g_emb (N x dim, stride ld_gemb)
+ * and g_rel; both must be zero-initialised (or hold gradients to add to).       */
+int lkg_transe_score_bwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb,
+                             const float *relemb, int64_t ld_rel, const int64_t *h,
+                             const int64_t *r, const int64_t *pos_t, const int64_t *neg_t,
+                             const float *pos, const float *neg, float lambda,
+                             const float *g_loss, float *g_emb, int64_t ld_gemb, float *g_rel,
+                             int64_t ld_grel, void *stream);
+
+/* K7  TransR projection W_r = gat_trans_M[r] (model.py:372, 390-395) without ever materialising the
+ * B x C x D gather: the batch is grouped by relation (stable counting sort), its entity rows are
+ * gathered in that order, and ONE grouped MFMA GEMM applies W_r per relation segment.
+ *
+ * lkg_group_by_key_i64: perm int32[n] lists input positions in key order (stable), seg int32[n_keys+1]
+ * the first position of each key.  Keys outside [0, n_keys) are clamped.                           */
+int lkg_group_by_key_i64(int64_t n, int32_t n_keys, const int64_t *keys, int32_t *perm, int32_t *seg,
+                         void *stream);
+/* dst[i,:] = src[idx[perm[i]],:]   (idx and/or perm may be NULL = identity)                         */
+int lkg_gather_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                        const int32_t *perm, float *dst, int64_t ldd, void *stream);
+/* dst[idx[perm[i]],:] += src[i,:]  (f32 atomics; autograd of the row gathers model.py:382-384)     */
+int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                             const int32_t *perm, float *dst, int64_t ldd, void *stream);
+/* dst[i] = src[perm[i]] for int64 ids                                                              */
+int lkg_gather_i64(int64_t n, const int64_t *src, const int32_t *perm, int64_t *dst, void *stream);
+
+/* Grouped fp32 MFMA GEMM over segments seg[g]..seg[g+1] (device int32[n_groups+1], no host sync):
+ *  mode 1 (rows): C[seg rows,:] = alpha * A[seg rows,:] opB(B + g*stride_b) + beta*C   (A row-major)
+ *                 max_seg_len bounds the longest segment (e.g. the batch size).
+ *  mode 2 (k)   : (C + g*stride_c)[m,n] = alpha * sum_{k in seg} A[k,m] B[k,n] + beta*C
+ *                 (A given transposed, trans_a = 1; B k-major, trans_b = 0): g_W[r] = X_r^T G_r.   */
+int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int64_t max_seg_len,
+                         int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
+                         const float *a, int64_t lda, const float *b, int64_t ldb, int64_t stride_b,
+                         float beta, float *c, int64_t ldc, int64_t stride_c, void *stream);
+
+/* Scores on already-projected rows (TransR form, model.py:413-426): same outputs
+ * as lkg_transe_score_fwd_f32 but ph/pp/pn are dense batch x dim matrices.       */
+int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,
+                            const float *pn, int64_t ld, const float *relemb, int64_t ld_rel,
+                            const int64_t *r, float *pos, float *neg, float *reg, float *rank,
+                            void *stream);
+int lkg_dense_score_bwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,
+                            const float *pn, int64_t ld, const float *relemb, int64_t ld_rel,
+                            const int64_t *r, const float *pos, const float *neg, float lambda,
+                            const float *g_loss, float *g_ph, float *g_pp, float *g_pn,
+                            int64_t ldg, float *g_rel, int64_t ld_grel, void *stream);
+
+/* K5  row-wise epilogue of an aggregation layer (model.py:111, 161, 305):
+ *   a   = leaky_relu(z, slope)                    (z = Linear output, n x d)
+ *   y   = layer_norm(a) * gamma + beta            (eps)
+ *   yn  = y / max(|y|_2, norm_eps)                (nullable: the L2-normalised copy)
+ * save_mean / save_rstd float[n] are kept for the backward.                       */
+int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
+                              const float *gamma, const float *beta, float eps, float *y,
+                              int64_t ldy, float *yn, int64_t ldyn, float norm_eps,
+                              float *save_mean, float *save_rstd, void *stream);
+
+/* Backward of the epilogue.  g_y and g_yn (nullable) are the upstream gradients of
+ * the two outputs; writes g_z (n x d) and ACCUMULATES g_gamma / g_beta (atomic,
+ * zero-initialised by the caller).                                                 */
+int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
+                              const float *gamma, const float *y, int64_t ldy,
+                              const float *save_mean, const float *save_rstd, const float *g_y,
+                              int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
+                              float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
+                              void *stream);
+
+/* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
+ *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)
+ * gpre / zpre already hold the Linear outputs INCLUDING their biases.              */
+int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
+                           int64_t ldg, const float *zpre, int64_t ldz, float *out, int64_t ldo,
+                           void *stream);
+int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
+                           int64_t ldg, const float *zpre, int64_t ldz, const float *g_out,
+                           int64_t ldgo, float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg,
+                           float *g_zpre, int64_t ldgz, void *stream);
+
+/* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
+int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
+
+/* Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32), row-major:
+ *   C[m,n] = alpha * sum_k opA(A)[m,k] * opB(B)[k,n] + beta * C[m,n] (+ bias[n])
+ * trans_a / trans_b: 0 = stored as written, 1 = stored transposed (A is k x m / B is n x k).
+ * Used for nn.Linear forward (trans_b = 1), its data gradient and its weight
+ * gradient (model.py:111 etc., gate.py:24-25, linear_gat model.py:309).          */
+int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
+                 const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                 int64_t ldc, const float *bias, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITERALKG_HIP_H */

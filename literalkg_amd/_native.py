@@ -1,0 +1,84 @@
+"""ctypes binding of include/literalkg_hip.h.  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblkg_hip.so")
+_lib = None
+
+i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/literalkg_hip.h
+PROTOTYPES = {
+    "lkg_version": [],
+    "lkg_last_error": [],
+    "lkg_csr_build": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lkg_csr_transpose": [i64, i64, i64, vp, vp, vp, vp, vp],
+    "lkg_row_partition": [i64, vp, i32, vp],
+    "lkg_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp],
+    "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp],
+    "lkg_permute_f32": [i64, vp, vp, vp, vp],
+    "lkg_transe_score_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lkg_loss_reduce_f32": [i64, vp, vp, f32, vp, vp],
+    "lkg_transe_score_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp, i64, vp],
+    "lkg_group_by_key_i64": [i64, i32, vp, vp, vp, vp],
+    "lkg_gather_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
+    "lkg_scatter_add_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
+    "lkg_gather_i64": [i64, vp, vp, vp, vp],
+    "lkg_grouped_gemm_f32": [i32, i32, vp, i64, i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, i64, f32, vp, i64,
+                             i64, vp],
+    "lkg_dense_score_fwd_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],
+    "lkg_dense_score_bwd_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp, vp, vp, vp, i64, vp, i64,
+                                vp],
+    "lkg_act_layernorm_fwd_f32": [i64, i32, vp, i64, f32, vp, vp, f32, vp, i64, vp, i64, f32, vp, vp, vp],
+    "lkg_act_layernorm_bwd_f32": [i64, i32, vp, i64, f32, vp, vp, i64, vp, vp, vp, i64, vp, i64, f32, vp, i64, vp,
+                                  vp, vp],
+    "lkg_gate_blend_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
+    "lkg_gate_blend_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
+    "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp],
+    "lkg_colsum_f32": [i64, i32, vp, i64, vp, vp],
+}
+_RESTYPE = {"lkg_last_error": C.c_char_p}
+
+
+class LkgError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the library once.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise LkgError(
+            f"{_LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m literalkg_amd.build`). "
+            "literalkg_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lkg_last_error()
+        raise LkgError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Raw pointer of a tensor / numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

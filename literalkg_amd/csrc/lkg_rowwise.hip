@@ -1,0 +1,345 @@
+// K5 row-wise epilogue of an aggregation layer (LeakyReLU -> LayerNorm -> L2-normalised copy,
+// model.py:111/161/305) and K6 literal-gate blend (gate.py:24-26), forward and backward.
+// All HBM-bound: each row is read once into registers (one wave per row, 16 bytes per lane per chunk),
+// every statistic is a wave xor-shuffle reduction, every output is written once.
+#include <algorithm>
+
+#include "lkg_common.h"
+
+namespace {
+
+// A row of d floats spread over one wave: lane l holds elements [(l + 64*i)*W, +W) for i < CPL.
+template <int W, int CPL>
+struct RowRegs {
+    float v[CPL * W];
+    __device__ __forceinline__ void load(const float *p, int d, int lane, float fill = 0.f) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int e = (lane + 64 * i) * W;
+            if constexpr (W == 4) {
+                if (e < d) {
+                    const float4 t = *reinterpret_cast<const float4 *>(p + e);
+                    v[i * 4 + 0] = t.x;
+                    v[i * 4 + 1] = t.y;
+                    v[i * 4 + 2] = t.z;
+                    v[i * 4 + 3] = t.w;
+                } else {
+                    v[i * 4 + 0] = v[i * 4 + 1] = v[i * 4 + 2] = v[i * 4 + 3] = fill;
+                }
+            } else {
+                v[i] = e < d ? p[e] : fill;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float *p, int d, int lane) const {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int e = (lane + 64 * i) * W;
+            if (e < d) {
+                if constexpr (W == 4)
+                    *reinterpret_cast<float4 *>(p + e) = make_float4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
+                else
+                    p[e] = v[i];
+            }
+        }
+    }
+    __device__ __forceinline__ bool live(int k, int d, int lane) const { return (lane + 64 * (k / W)) * W + (k % W) < d; }
+};
+
+template <int W, int CPL>
+__global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                          float slope, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float *__restrict__ y, long ldy, float *__restrict__ yn,
+                                                          long ldyn, float norm_eps, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_rstd) {
+    constexpr int K = CPL * W;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    RowRegs<W, CPL> a, g, b;
+    a.load(z + row * ldz, d, lane);
+    g.load(gamma, d, lane);
+    b.load(beta, d, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float t = a.v[k];
+        a.v[k] = t > 0.f ? t : t * slope;
+        s += a.live(k, d, lane) ? a.v[k] : 0.f;
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float c = a.live(k, d, lane) ? a.v[k] - mean : 0.f;
+        q = fmaf(c, c, q);
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float o = (a.v[k] - mean) * rstd * g.v[k] + b.v[k];
+        a.v[k] = o;
+        nn += a.live(k, d, lane) ? o * o : 0.f;
+    }
+    a.store(y + row * ldy, d, lane);
+    if (lane == 0) {
+        save_mean[row] = mean;
+        save_rstd[row] = rstd;
+    }
+    if (yn) {
+        const float inv = 1.f / fmaxf(sqrtf(wave_sum(nn)), norm_eps);
+#pragma unroll
+        for (int k = 0; k < K; ++k) a.v[k] *= inv;
+        a.store(yn + row * ldyn, d, lane);
+    }
+}
+
+// Backward.  With a = leaky(z), xh = (a - mean) * rstd, y = xh * gamma + beta, yn = y / max(|y|, e):
+//   G   = g_y + (g_yn - yn * <yn, g_yn>) / max(|y|, e)      (second term only when |y| > e; else g_yn / e)
+//   dxh = G * gamma ;  da = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)) ;  dz = da * leaky'(z)
+//   g_gamma += sum_rows G * xh ;  g_beta += sum_rows G
+template <int W, int CPL>
+__global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                          float slope, const float *__restrict__ gamma,
+                                                          const float *__restrict__ y, long ldy,
+                                                          const float *__restrict__ save_mean,
+                                                          const float *__restrict__ save_rstd,
+                                                          const float *__restrict__ g_y, long ldgy,
+                                                          const float *__restrict__ g_yn, long ldgyn, float norm_eps,
+                                                          float *__restrict__ g_z, long ldgz,
+                                                          float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+    constexpr int K = CPL * W;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    RowRegs<W, CPL> gam;
+    gam.load(gamma, d, lane);
+    float acc_g[K], acc_b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc_g[k] = acc_b[k] = 0.f;
+
+    for (long row = wave; row < n; row += nwaves) {
+        RowRegs<W, CPL> zz, G, yy;
+        zz.load(z + row * ldz, d, lane);
+        if (g_y)
+            G.load(g_y + row * ldgy, d, lane);
+        else
+            G.load(z, 0, lane);   // zeros
+        if (g_yn) {
+            RowRegs<W, CPL> gn;
+            yy.load(y + row * ldy, d, lane);
+            gn.load(g_yn + row * ldgyn, d, lane);
+            float n2 = 0.f, dt = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                n2 = fmaf(yy.v[k], yy.v[k], n2);
+                dt = fmaf(yy.v[k], gn.v[k], dt);
+            }
+            const float nrm = sqrtf(wave_sum(n2));
+            dt = wave_sum(dt);
+            if (nrm > norm_eps) {
+                const float inv = 1.f / nrm;
+                const float proj = dt * inv * inv * inv;   // <y,g>/|y|^3
+#pragma unroll
+                for (int k = 0; k < K; ++k) G.v[k] += gn.v[k] * inv - yy.v[k] * proj;
+            } else {
+                const float inv = 1.f / norm_eps;
+#pragma unroll
+                for (int k = 0; k < K; ++k) G.v[k] += gn.v[k] * inv;
+            }
+        }
+        const float mean = save_mean[row], rstd = save_rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+        float xh[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float t = zz.v[k];
+            const float a = t > 0.f ? t : t * slope;
+            const bool lv = zz.live(k, d, lane);
+            xh[k] = lv ? (a - mean) * rstd : 0.f;
+            const float dx = G.v[k] * gam.v[k];
+            s1 += dx;
+            s2 = fmaf(dx, xh[k], s2);
+            acc_g[k] = fmaf(G.v[k], xh[k], acc_g[k]);
+            acc_b[k] += G.v[k];
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float dx = G.v[k] * gam.v[k];
+            const float da = rstd * (dx - s1 - xh[k] * s2);
+            zz.v[k] = da * (zz.v[k] > 0.f ? 1.f : slope);
+        }
+        zz.store(g_z + row * ldgz, d, lane);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = (lane + 64 * (k / W)) * W + (k % W);
+        if (e < d) {
+            atomicAdd(g_gamma + e, acc_g[k]);
+            atomicAdd(g_beta + e, acc_b[k]);
+        }
+    }
+}
+
+__global__ void gate_blend_fwd_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                      const float *__restrict__ gpre, long ldg, const float *__restrict__ zpre,
+                                      long ldz, float *__restrict__ out, long ldo) {
+    const long total = n * d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d;
+        const int c = (int)(i - r * d);
+        const float s = sigmoidf_(zpre[r * ldz + c]);
+        const float tg = tanhf(gpre[r * ldg + c]);
+        out[r * ldo + c] = (1.f - s) * x[r * ldx + c] + s * tg;
+    }
+}
+
+__global__ void gate_blend_bwd_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                      const float *__restrict__ gpre, long ldg, const float *__restrict__ zpre,
+                                      long ldz, const float *__restrict__ g_out, long ldgo, float *__restrict__ g_x,
+                                      long ldgx, float *__restrict__ g_gpre, long ldgg, float *__restrict__ g_zpre,
+                                      long ldgz) {
+    const long total = n * d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d;
+        const int c = (int)(i - r * d);
+        const float s = sigmoidf_(zpre[r * ldz + c]);
+        const float tg = tanhf(gpre[r * ldg + c]);
+        const float go = g_out[r * ldgo + c];
+        g_x[r * ldgx + c] = go * (1.f - s);
+        g_gpre[r * ldgg + c] = go * s * (1.f - tg * tg);
+        g_zpre[r * ldgz + c] = go * (tg - x[r * ldx + c]) * s * (1.f - s);
+    }
+}
+
+template <int W>
+int pick_cpl(int d) {
+    const int chunks = (d + W - 1) / W;
+    const int cpl = (chunks + 63) / 64;
+    return cpl;
+}
+
+}  // namespace
+
+#define LKG_ROW_DISPATCH(KERNEL, GRID, ...)                                                                      \
+    do {                                                                                                         \
+        if (vec) {                                                                                               \
+            switch (pick_cpl<4>(d)) {                                                                            \
+                case 1: hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 2: hipLaunchKernelGGL((KERNEL<4, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 3: hipLaunchKernelGGL((KERNEL<4, 3>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 4: hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                default: lkg_set_error("row width %d > 1024 not supported", d); return LKG_ERR_UNSUPPORTED;      \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            switch (pick_cpl<1>(d)) {                                                                            \
+                case 1: hipLaunchKernelGGL((KERNEL<1, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 2: hipLaunchKernelGGL((KERNEL<1, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 3: hipLaunchKernelGGL((KERNEL<1, 3>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                case 4: hipLaunchKernelGGL((KERNEL<1, 4>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+                default:                                                                                         \
+                    lkg_set_error("row width %d > 256 needs 16-byte aligned rows (d %% 4 == 0)", d);             \
+                    return LKG_ERR_UNSUPPORTED;                                                                  \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+
+extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
+                                         const float *gamma, const float *beta, float eps, float *y, int64_t ldy,
+                                         float *yn, int64_t ldyn, float norm_eps, float *save_mean, float *save_rstd,
+                                         void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldy >= d && (!yn || ldyn >= d), "lkg_act_layernorm_fwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(z && gamma && beta && y && save_mean && save_rstd, "lkg_act_layernorm_fwd_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = d % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && (!yn || ldyn % 4 == 0) && lkg_aligned16(z) &&
+                     lkg_aligned16(y) && lkg_aligned16(gamma) && lkg_aligned16(beta) && (!yn || lkg_aligned16(yn));
+    const dim3 grid((unsigned)((n + 3) / 4));
+    LKG_ROW_DISPATCH(act_ln_fwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, beta, eps, y, (long)ldy, yn,
+                     (long)ldyn, norm_eps, save_mean, save_rstd);
+    LKG_CHECK_LAUNCH("lkg_act_layernorm_fwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
+                                         const float *gamma, const float *y, int64_t ldy, const float *save_mean,
+                                         const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
+                                         int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
+                                         float *g_beta, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
+    LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(z && gamma && save_mean && save_rstd && g_z && g_gamma && g_beta && (!g_yn || y),
+                "lkg_act_layernorm_bwd_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = d % 4 == 0 && ldz % 4 == 0 && ldgz % 4 == 0 && (!g_y || ldgy % 4 == 0) &&
+                     (!g_yn || (ldgyn % 4 == 0 && ldy % 4 == 0)) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
+                     lkg_aligned16(gamma) && (!g_y || lkg_aligned16(g_y)) &&
+                     (!g_yn || (lkg_aligned16(g_yn) && lkg_aligned16(y)));
+    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 2048));
+    LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
+                     save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta);
+    LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
+                                      int64_t ldg, const float *zpre, int64_t ldz, float *out, int64_t ldo,
+                                      void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldg >= d && ldz >= d && ldo >= d, "lkg_gate_blend_fwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x && gpre && zpre && out, "lkg_gate_blend_fwd_f32: null pointer");
+    const int64_t blocks = std::min<int64_t>((n * d + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(gate_blend_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, x,
+                       (long)ldx, gpre, (long)ldg, zpre, (long)ldz, out, (long)ldo);
+    LKG_CHECK_LAUNCH("lkg_gate_blend_fwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
+                                      int64_t ldg, const float *zpre, int64_t ldz, const float *g_out, int64_t ldgo,
+                                      float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg, float *g_zpre,
+                                      int64_t ldgz, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldg >= d && ldz >= d && ldgo >= d && ldgx >= d && ldgg >= d && ldgz >= d,
+                "lkg_gate_blend_bwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x && gpre && zpre && g_out && g_x && g_gpre && g_zpre, "lkg_gate_blend_bwd_f32: null pointer");
+    const int64_t blocks = std::min<int64_t>((n * d + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(gate_blend_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, x,
+                       (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx, g_gpre,
+                       (long)ldgg, g_zpre, (long)ldgz);
+    LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_f32");
+    return LKG_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void colsum_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                                      float *__restrict__ out, long rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += x[r * ldx + c];
+        atomicAdd(out + c, s);
+    }
+}
+}  // namespace
+
+extern "C" int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && out, "lkg_colsum_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * d, s) != hipSuccess) {
+        lkg_set_error("lkg_colsum_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x, "lkg_colsum_f32: null pointer");
+    const long blocks = std::min<int64_t>((n + 63) / 64, 2048);
+    const long rpb = (n + blocks - 1) / blocks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (long)n, d, x, (long)ldx, out, rpb);
+    LKG_CHECK_LAUNCH("lkg_colsum_f32");
+    return LKG_OK;
+}

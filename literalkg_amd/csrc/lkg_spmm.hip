@@ -1,0 +1,201 @@
+// K3 / K4: neighbour aggregation  out[i,:] = sum_j val[j] * x[col[j],:]  over a CSR
+// (forward, model.py:106) or the CSC of the same pattern (backward, A^T grad).
+//
+// HBM-bound gather.  Mapping for gfx950 (wave64):
+//   * one wave per destination row (softmax rows and aggregation rows are the same unit);
+//   * the row's (col, val) pairs are fetched with ONE coalesced load per 64 entries and
+//     handed to the gathering lanes by cross-lane reads (readlane / ds_bpermute), so the
+//     index stream costs one dword per entry, not one per lane;
+//   * a source row is read as whole 16-byte chunks by consecutive lanes: D=256 is exactly one
+//     global_load_dwordx4 per lane per edge (1 KiB per wave-instruction).  For narrower rows the
+//     wave is split into 64/LPE sub-groups that gather different edges at once and are summed
+//     with xor-shuffles at the end, so every lane always carries a 16-byte load;
+//   * U edges are kept in flight per sub-group (unrolled, loads issued before the FMAs).
+#include <algorithm>
+
+#include "lkg_common.h"
+
+namespace {
+
+template <typename V>
+struct vec_ops;
+template <>
+struct vec_ops<float4> {
+    static constexpr int W = 4;
+    static __device__ __forceinline__ float4 zero() { return f4_zero(); }
+    static __device__ __forceinline__ void fma(float4 &a, float s, const float4 &x) { f4_fma(a, s, x); }
+    template <int M>
+    static __device__ __forceinline__ void xor_add(float4 &a) {
+        a.x += __shfl_xor(a.x, M, 64);
+        a.y += __shfl_xor(a.y, M, 64);
+        a.z += __shfl_xor(a.z, M, 64);
+        a.w += __shfl_xor(a.w, M, 64);
+    }
+};
+template <>
+struct vec_ops<float> {
+    static constexpr int W = 1;
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ void fma(float &a, float s, const float &x) { a = fmaf(s, x, a); }
+    template <int M>
+    static __device__ __forceinline__ void xor_add(float &a) { a += __shfl_xor(a, M, 64); }
+};
+
+template <typename V, int LPE>
+__device__ __forceinline__ void reduce_subgroups(V &a) {
+    if constexpr (LPE <= 32) vec_ops<V>::template xor_add<32>(a);
+    if constexpr (LPE <= 16) vec_ops<V>::template xor_add<16>(a);
+    if constexpr (LPE <= 8) vec_ops<V>::template xor_add<8>(a);
+}
+
+// V: float4 (16-byte chunks) or float.  LPE: lanes per edge.  CPL: chunks per lane.  U: edges in flight.
+// FULL: nchunk == LPE * CPL, i.e. no lane ever falls outside the row (drops the per-load guard).
+//
+// The edge loop is branch-free on purpose: a predicated gather (`ok ? load : 0`) makes hipcc emit a
+// branch per load and, at the joins, a conservative s_waitcnt vmcnt(0) that serialises the U gathers.
+// Instead the tail slots of the last group re-read the row's last valid source row (an L1 hit) with
+// weight 0.
+template <typename V, int LPE, int CPL, int U, bool FULL>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
+                                                        const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col,
+                                                        const float *__restrict__ val,
+                                                        const float *__restrict__ x, long ldx,
+                                                        float *__restrict__ out, long ldo) {
+    using ops = vec_ops<V>;
+    constexpr int EPW = 64 / LPE;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    const int sub = lane / LPE;
+    const int sl = lane % LPE;
+
+    V acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
+
+    for (int base = start; base < end; base += 64) {
+        const int cnt = min(64, end - base);
+        const int last = cnt - 1;
+        // one coalesced fetch of up to 64 (col, val) pairs; lanes past the row end copy its last entry
+        const int c = col[base + min(lane, last)];
+        const float v = val[base + min(lane, last)];
+        for (int k = 0; k < cnt; k += EPW * U) {
+            int cc[U];
+            float vv[U];
+            V xv[U][CPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = k + u * EPW + sub;
+                const int idc = min(idx, last);
+                if constexpr (LPE == 64) {   // idx is wave-uniform: scalar broadcast
+                    cc[u] = __builtin_amdgcn_readlane(c, idc);
+                    vv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), idc));
+                } else {
+                    cc[u] = __shfl(c, idc, 64);
+                    vv[u] = __shfl(v, idc, 64);
+                }
+                vv[u] = idx < cnt ? vv[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V *src = reinterpret_cast<const V *>(x + (long)cc[u] * ldx);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    const int chunk = sl + i * LPE;
+                    if constexpr (FULL)
+                        xv[u][i] = src[chunk];
+                    else
+                        xv[u][i] = src[min(chunk, nchunk - 1)];   // clamped lanes are never stored
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) ops::fma(acc[i], vv[u], xv[u][i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
+    if (sub == 0) {
+        V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int chunk = sl + i * LPE;
+            if (FULL || chunk < nchunk) dst[chunk] = acc[i];
+        }
+    }
+}
+
+template <typename V, int LPE, int CPL, int U, bool FULL>
+int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
+           int64_t ldx, float *out, int64_t ldo, hipStream_t s) {
+    const int rows_per_block = 4;
+    const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows,
+                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo);
+    LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
+    return LKG_OK;
+}
+
+template <typename V>
+int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
+             int64_t ldx, float *out, int64_t ldo, hipStream_t s) {
+#define LKG_GO(LPE, CPL, U)                                                                              \
+    return (nchunk == LPE * CPL)                                                                         \
+               ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, s)     \
+               : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, s)
+    if (nchunk <= 8) LKG_GO(8, 1, 4);
+    if (nchunk <= 16) LKG_GO(16, 1, 4);
+    if (nchunk <= 32) LKG_GO(32, 1, 4);
+    if (nchunk <= 64) LKG_GO(64, 1, 4);
+    if (nchunk <= 128) LKG_GO(64, 2, 4);
+    if (nchunk <= 192) LKG_GO(64, 3, 2);
+    LKG_GO(64, 4, 2);
+#undef LKG_GO
+}
+
+}  // namespace
+
+extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                                const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
+                                void *stream) {
+    LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
+    LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
+    LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
+                (long long)ldo, d);
+    if (n_rows == 0) return LKG_OK;
+    LKG_REQUIRE(rowptr && x && out, "lkg_spmm_csr_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out);
+    const int width = vec ? 4 : 1;
+    const int block_cols = 256 * width;   // columns one launch covers (CPL <= 4)
+    for (int c0 = 0; c0 < d; c0 += block_cols) {
+        const int dc = min(block_cols, d - c0);
+        int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, s)
+                     : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo, s);
+        if (rc != LKG_OK) return rc;
+    }
+    return LKG_OK;
+}
+
+// dst[i] = src[perm[i]]
+__global__ void permute_kernel(long n, const int *__restrict__ perm, const float *__restrict__ src,
+                               float *__restrict__ dst) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[perm[i]];
+}
+
+extern "C" int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src, float *dst, void *stream) {
+    LKG_REQUIRE(n >= 0, "lkg_permute_f32: negative n");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(perm && src && dst, "lkg_permute_f32: null pointer");
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, perm, src,
+                       dst);
+    LKG_CHECK_LAUNCH("lkg_permute_f32");
+    return LKG_OK;
+}

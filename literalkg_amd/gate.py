@@ -1,0 +1,54 @@
+"""Literal gates (LiteralE-style) on the HIP path.
+
+Parameter names and shapes follow the reference's ``GateMul`` / ``Gate`` (gate.py:5-51) so that
+checkpoints interchange.  The arithmetic differs in structure: the reference concatenates
+``[x | num | txt]`` (an N x (D+302) copy) before ``g``; here ``g.weight`` is addressed as column
+panels and every panel is one accumulating MFMA GEMM, then a single fused blend kernel applies
+tanh / sigmoid / mix (K6).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class GateMul(nn.Module):
+    """Both literal kinds: g over [x | num | txt], z over three bias-free projections (gate.py:5-28)."""
+
+    def __init__(self, emb_size, num_lit_size, txt_lit_size):
+        super().__init__()
+        self.emb_size, self.num_lit_size, self.txt_lit_size = emb_size, num_lit_size, txt_lit_size
+        self.g = nn.Linear(emb_size + num_lit_size + txt_lit_size, emb_size)
+        self.gate_ent = nn.Linear(emb_size, emb_size, bias=False)
+        self.gate_num_lit = nn.Linear(num_lit_size, emb_size, bias=False)
+        self.gate_txt_lit = nn.Linear(txt_lit_size, emb_size, bias=False)
+        self.gate_bias = nn.Parameter(torch.zeros(emb_size))
+
+    def forward(self, x_ent, x_lit_num, x_lit_txt):
+        d, n = self.emb_size, self.num_lit_size
+        wg = self.g.weight
+        gpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt), (wg[:, :d], wg[:, d:d + n], wg[:, d + n:]),
+                                self.g.bias)
+        zpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt),
+                                (self.gate_ent.weight, self.gate_num_lit.weight, self.gate_txt_lit.weight),
+                                self.gate_bias)
+        return ops.gate_blend(x_ent, gpre, zpre)
+
+
+class Gate(nn.Module):
+    """One literal kind (gate.py:30-51)."""
+
+    def __init__(self, emb_size, lit_size):
+        super().__init__()
+        self.emb_size, self.lit_size = emb_size, lit_size
+        self.g = nn.Linear(emb_size + lit_size, emb_size)
+        self.gate_ent = nn.Linear(emb_size, emb_size, bias=False)
+        self.gate_lit = nn.Linear(lit_size, emb_size, bias=False)
+        self.gate_bias = nn.Parameter(torch.zeros(emb_size))
+
+    def forward(self, x_ent, x_lit):
+        d = self.emb_size
+        wg = self.g.weight
+        gpre = ops.multi_linear((x_ent, x_lit), (wg[:, :d], wg[:, d:]), self.g.bias)
+        zpre = ops.multi_linear((x_ent, x_lit), (self.gate_ent.weight, self.gate_lit.weight), self.gate_bias)
+        return ops.gate_blend(x_ent, gpre, zpre)

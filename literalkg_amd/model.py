@@ -1,0 +1,346 @@
+"""Drop-in ``LiteralKG`` module for MI355X: the reference's nn.Module surface
+(``LiteralKG(args, n_entities, n_relations, A_in, numerical_literals, text_literals)``;
+``model(*input, device=, mode=)``; same ``state_dict`` keys, model.py:167-263, 521-532) over the
+HIP kernels of ``include/literalkg_hip.h``.
+
+Differences in *structure* (results are the reference's):
+  * ``A_in`` stays a sparse COO ``nn.Parameter`` for ``state_dict`` / checkpoint interchange, but the
+    kernels read a destination-sorted int32 CSR (+ CSC for the backward) built once per pattern and a
+    flat fp32 value array that aliases ``A_in``'s values (``graph.py``);
+  * ``update_att`` runs fused on the device (no ``.cpu()`` round trip, model.py:470);
+  * ``gat_trans_M[r]`` is never gathered into a B x C x D tensor (model.py:372): the batch is grouped
+    by relation and projected by one grouped MFMA GEMM;
+  * the gate never concatenates ``[x | num | txt]`` (gate.py:23).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .gate import Gate, GateMul
+from .graph import KGStructure
+
+
+class AttentionCSR:
+    """What an aggregation layer needs of A_in on the device: pattern + values in CSR and CSC order."""
+
+    def __init__(self, graph: KGStructure, val: torch.Tensor, val_t: Optional[torch.Tensor] = None):
+        self.graph = graph
+        self.val = val
+        self.val_t = val_t if val_t is not None else (
+            ops.permute_values(val, graph.t_perm) if graph.t_perm is not None and val.is_cuda else None)
+
+    def aggregate(self, ego: torch.Tensor) -> torch.Tensor:
+        return ops.aggregate(ego, self.graph, self.val, self.val_t)
+
+
+def _xavier(linear: nn.Linear) -> nn.Linear:
+    nn.init.xavier_uniform_(linear.weight)
+    return linear
+
+
+class Aggregator(nn.Module):
+    """One aggregation layer (model.py:12-164): side = A_in @ ego, then the type-specific dense part,
+    LeakyReLU, LayerNorm, dropout.  Parameter names/shapes are the reference's."""
+
+    def __init__(self, in_dim, out_dim, dropout, aggregator_type, use_residual=False, args=None):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.dropout = dropout
+        self.aggregator_type = aggregator_type
+        self.use_residual = bool(use_residual)
+        kind = aggregator_type
+        if kind not in ("gcn", "graphsage", "bi-interaction", "gin"):
+            raise NotImplementedError(kind)
+        mix_dim = args.mlp_hidden_dim if kind == "gin" else in_dim
+        # identity-mapping matrix of the GCNII-style residual; always registered (model.py:21, 61)
+        self.weight = nn.Parameter(torch.empty(mix_dim, mix_dim))
+        bound = 1.0 / math.sqrt(out_dim)
+        nn.init.uniform_(self.weight, -bound, bound)   # reference leaves the gin variant uninitialised
+        if self.use_residual or kind == "gin":
+            self.linear_h0 = _xavier(nn.Linear(args.embed_dim, mix_dim))
+        self.layer_normalize = nn.LayerNorm(out_dim)
+        if kind == "gcn":
+            self.linear = _xavier(nn.Linear(in_dim, out_dim))
+        elif kind == "graphsage":
+            if self.use_residual:
+                self.linear_h = _xavier(nn.Linear(2 * in_dim, in_dim))
+                self.linear = _xavier(nn.Linear(in_dim, out_dim))
+            else:
+                self.linear = _xavier(nn.Linear(2 * in_dim, out_dim))
+        elif kind == "bi-interaction":
+            self.linear1 = _xavier(nn.Linear(in_dim, out_dim))
+            self.linear2 = _xavier(nn.Linear(in_dim, out_dim))
+        else:   # gin: an MLP on (ego + side); its Linears keep torch's default init like the reference
+            self.num_layers = args.n_mlp_layers
+            if self.num_layers == 1:
+                self.linear = nn.Linear(in_dim, out_dim)
+            else:
+                hid = args.mlp_hidden_dim
+                self.inp_linear = nn.Linear(in_dim, hid)
+                self.linears = nn.ModuleList(nn.Linear(hid, hid) for _ in range(self.num_layers - 1))
+                self.out_linear = nn.Linear(hid, out_dim)
+                self.mlp_layer_norms = nn.ModuleList(nn.LayerNorm(hid) for _ in range(self.num_layers - 1))
+        self.last_normalized = None
+
+    # (1-a) hi + a W0 h0, then @ ((1-b) + b W)   -- (1-b) lands on every entry of W (model.py:96)
+    def residual_connection(self, hi, h0, lamda, alpha, l):
+        if not self.use_residual:
+            return hi
+        h0p = ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
+        mixed = (1 - alpha) * hi + alpha * h0p
+        beta = math.log(lamda / l + 1)
+        return ops.matmul(mixed, (1 - beta) + beta * self.weight)
+
+    @staticmethod
+    def _lin(mod: nn.Linear, x):
+        return ops.linear(x, mod.weight, mod.bias)
+
+    def _finish(self, z, extra_sum=None):
+        """LeakyReLU -> LayerNorm (-> dropout), and the L2-normalised copy when it can be fused."""
+        ln = self.layer_normalize
+        drop = self.training and self.dropout > 0
+        if extra_sum is None:
+            y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=not drop)
+        else:   # gin skip-sum: LN(act(z)) + earlier layers, then LN again (model.py:151-161)
+            inner, _ = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=False)
+            total = inner
+            for e in extra_sum:
+                total = total + e
+            # second LayerNorm has no activation in front: slope 1 makes LeakyReLU the identity
+            y, yn = ops.act_layernorm(total, ln.weight, ln.bias, want_norm=not drop, slope=1.0)
+        if drop:
+            y = F.dropout(y, self.dropout, True)
+            yn = None
+        self.last_normalized = yn
+        return y
+
+    def forward(self, ego_embeddings, A_in: AttentionCSR, all_layers, lamda, alpha, l):
+        ego = ego_embeddings
+        side = A_in.aggregate(ego)
+        h0 = all_layers[0]
+        kind = self.aggregator_type
+        if kind == "gcn":
+            z = self._lin(self.linear, self.residual_connection(ego + side, h0, lamda, alpha, l))
+            return self._finish(z)
+        if kind == "graphsage":
+            if self.use_residual:
+                wh = self.linear_h.weight
+                hi = ops.multi_linear((ego, side), (wh[:, :self.in_dim], wh[:, self.in_dim:]), self.linear_h.bias)
+                z = self._lin(self.linear, self.residual_connection(hi, h0, lamda, alpha, l))
+            else:   # Linear over [ego | side] as two accumulating GEMMs, no cat
+                w = self.linear.weight
+                z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
+            return self._finish(z)
+        if kind == "bi-interaction":
+            s = self._lin(self.linear1, self.residual_connection(ego + side, h0, lamda, alpha, l))
+            b = self._lin(self.linear2, self.residual_connection(ego * side, h0, lamda, alpha, l))
+            # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): do it here, then a
+            # slope-1 epilogue for the LayerNorm
+            z = F.leaky_relu(b, ops.LEAKY_SLOPE) + F.leaky_relu(s, ops.LEAKY_SLOPE)
+            ln = self.layer_normalize
+            drop = self.training and self.dropout > 0
+            y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=not drop, slope=1.0)
+            if drop:
+                y, yn = F.dropout(y, self.dropout, True), None
+            self.last_normalized = yn
+            return y
+        # gin (model.py:131-158)
+        if self.num_layers == 1:
+            raise AttributeError("gin with n_mlp_layers == 1 cannot run in the reference either "
+                                 "(inp_linear/out_linear are never created, model.py:66-68, 133)")
+        stack = self._lin(self.inp_linear, ego)
+        h = self._lin(self.inp_linear, ego + side)
+        for lin, norm in zip(self.linears, self.mlp_layer_norms):
+            h, _ = ops.act_layernorm(self._lin(lin, h), norm.weight, norm.bias, want_norm=False)
+            stack = stack + h
+        x = self.residual_connection(stack, h0, lamda, alpha, l)
+        z = self._lin(self.out_linear, x)
+        if len(all_layers) > 1:
+            return self._finish(z, extra_sum=list(all_layers[1:]))
+        return self._finish(z)
+
+
+class LiteralKG(nn.Module):
+    """See module docstring.  ``scoring``: 'transr' = model.py:364-428 (default), 'transe' =
+    model_bce.py:329-368 (no ``gat_trans_M``; needs the encoder width to equal ``relation_dim``)."""
+
+    def __init__(self, args, n_entities, n_relations, A_in=None, numerical_literals=None, text_literals=None,
+                 scoring: str = "transr"):
+        super().__init__()
+        if scoring not in ("transr", "transe"):
+            raise ValueError(scoring)
+        self.scoring = scoring
+        self.args = args
+        self.use_pretrain = args.use_pretrain
+        self.device = args.device
+        self.n_entities, self.n_relations = n_entities, n_relations
+        self.embed_dim, self.relation_dim = args.embed_dim, args.relation_dim
+        self.scale_gat_dim = args.scale_gat_dim
+        self.use_residual, self.alpha, self.lamda = args.use_residual, args.alpha, args.lamda
+        self.aggregation_type = args.aggregation_type
+        self.n_layers = args.n_conv_layers
+        self.conv_dim_list = [args.embed_dim] + [args.conv_dim] * self.n_layers
+        self.total_conv_dim = sum(self.conv_dim_list)
+        self.mess_dropout = [args.mess_dropout] * self.n_layers
+        self.kg_l2loss_lambda = args.kg_l2loss_lambda
+        self.prediction_l2loss_lambda = args.fine_tuning_l2loss_lambda
+        self.pre_training_neg_rate = args.pre_training_neg_rate
+        self.fine_tuning_neg_rate = args.fine_tuning_neg_rate
+        self.n_num_lit, self.n_txt_lit = args.num_lit_dim, args.txt_lit_dim
+        self.milestone_score = args.milestone_score
+
+        self.entity_embed = nn.Embedding(n_entities, self.embed_dim)
+        self.relation_embed = nn.Embedding(n_relations, self.relation_dim)
+        out_width = self.total_conv_dim
+        if self.scale_gat_dim is not None:
+            self.linear_gat = _xavier(nn.Linear(self.total_conv_dim, self.scale_gat_dim))
+            out_width = self.scale_gat_dim
+        self.out_width = out_width
+        if scoring == "transr":
+            self.gat_trans_M = nn.Parameter(torch.empty(n_relations, out_width, self.relation_dim))
+            nn.init.xavier_uniform_(self.gat_trans_M)
+        nn.init.xavier_uniform_(self.entity_embed.weight)
+        nn.init.xavier_uniform_(self.relation_embed.weight)
+
+        self.numerical_literals_embed = numerical_literals
+        self.text_literals_embed = text_literals
+        if args.use_num_lit and args.use_txt_lit:
+            self.emb_mul_lit = GateMul(self.embed_dim, self.n_num_lit, self.n_txt_lit)
+        elif args.use_num_lit:
+            self.emb_num_lit = Gate(self.embed_dim, self.n_num_lit)
+        elif args.use_txt_lit:
+            self.emb_txt_lit = Gate(self.embed_dim, self.n_txt_lit)
+
+        self.aggregator_layers = nn.ModuleList(
+            Aggregator(self.conv_dim_list[k], self.conv_dim_list[k + 1], self.mess_dropout[k], self.aggregation_type,
+                       self.use_residual, args) for k in range(self.n_layers))
+
+        # sparse, non-trainable, rides in state_dict like the reference's (model.py:257-261)
+        empty = torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0), (n_entities, n_entities))
+        self.A_in = nn.Parameter(empty, requires_grad=False)
+        if A_in is not None:
+            self.A_in.data = A_in
+        self._att: Optional[AttentionCSR] = None
+        self._att_key = None
+        self._triple_graph = None
+        self._triple_key = None
+        self.last_scores = {}
+
+    # ------------------------------------------------------------------ A_in <-> CSR
+    def _attention(self) -> AttentionCSR:
+        """CSR/CSC view of the current ``A_in`` (rebuilt only when ``A_in`` was replaced or moved)."""
+        a = self.A_in.data
+        if not a.is_coalesced():
+            a = a.coalesce()
+            self.A_in.data = a
+        vals = a._values()
+        key = (a._indices().data_ptr(), vals.data_ptr(), vals._version, str(vals.device), a._nnz())
+        if self._att is not None and self._att_key == key:
+            return self._att
+        graph = KGStructure.from_coo(a, device=vals.device)
+        self._att = AttentionCSR(graph, vals.contiguous())
+        self._att_key = key
+        return self._att
+
+    # ------------------------------------------------------------------ a6/a7 encoder
+    def gate_embeddings(self):
+        ent = self.entity_embed.weight
+        a = self.args
+        if a.use_num_lit:
+            self.numerical_literals_embed = self.numerical_literals_embed.to(self.device)
+        if a.use_txt_lit:
+            self.text_literals_embed = self.text_literals_embed.to(self.device)
+        if a.use_num_lit and a.use_txt_lit:
+            return self.emb_mul_lit(ent, self.numerical_literals_embed, self.text_literals_embed)
+        if a.use_num_lit:
+            return self.emb_num_lit(ent, self.numerical_literals_embed)
+        if a.use_txt_lit:
+            return self.emb_txt_lit(ent, self.text_literals_embed)
+        return ent
+
+    def gat_embeddings(self):
+        att = self._attention()
+        cur = self.gate_embeddings()
+        kept = [cur]
+        for idx, layer in enumerate(self.aggregator_layers):
+            cur = layer(cur, att, kept, self.lamda, self.alpha, idx + 1)
+            norm = layer.last_normalized
+            if norm is None:   # dropout active: the normalised copy is taken after the mask (model.py:304-305)
+                norm = F.normalize(cur, p=2.0, dim=1)
+            kept.append(norm)
+        cat = torch.cat(kept, dim=1)
+        if self.scale_gat_dim is not None:
+            return F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
+        return cat
+
+    # ------------------------------------------------------------------ a8/a9 loss
+    def calc_triplet_loss(self, h, r, pos_t, neg_t):
+        self.gat_embed = self.gat_embeddings()
+        keep = self.last_scores if not self.training else None
+        if self.scoring == "transr":
+            return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
+                                   self.kg_l2loss_lambda, keep)
+        return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
+                               self.kg_l2loss_lambda, keep)
+
+    # ------------------------------------------------------------------ a4/a5 attention refresh
+    def _structure_for(self, h_list, t_list, r_list, relations) -> KGStructure:
+        key = (h_list.data_ptr(), t_list.data_ptr(), r_list.data_ptr(), h_list.numel(), h_list._version,
+               t_list._version, r_list._version, tuple(relations) if relations is not None else None,
+               str(self.A_in.device))
+        if self._triple_graph is not None and self._triple_key == key:
+            return self._triple_graph
+        h, t, r = h_list, t_list, r_list
+        if relations is not None:
+            rel_ids = torch.as_tensor(list(relations), dtype=r.dtype, device=r.device)
+            present = torch.unique(r)
+            if not bool(torch.isin(present, rel_ids).all()):   # the reference only visits `relations`
+                keep = torch.isin(r, rel_ids)
+                h, t, r = h[keep], t[keep], r[keep]
+        g = KGStructure.from_triples(self.n_entities, h, t, r, device=self.A_in.device)
+        self._triple_graph, self._triple_key = g, key
+        return g
+
+    def update_attention(self, h_list, t_list, r_list, relations):
+        g = self._structure_for(h_list, t_list, r_list, relations)
+        val, _ = ops.edge_softmax(g, self.entity_embed.weight.detach(), self.relation_embed.weight.detach())
+        new = torch.sparse_coo_tensor(g.coo_indices(), val, (self.n_entities, self.n_entities), is_coalesced=True)
+        self.A_in.data = new
+        vals = new._values()
+        self._att = AttentionCSR(g, vals)
+        self._att_key = (new._indices().data_ptr(), vals.data_ptr(), vals._version, str(vals.device), new._nnz())
+
+    # ------------------------------------------------------------------ f1 heads
+    def calc_score(self, head_ids, tail_ids):
+        emb = self.gat_embeddings()
+        return ops.gemm(ops.gather_rows(emb.detach(), head_ids), ops.gather_rows(emb.detach(), tail_ids),
+                        trans_b=True)
+
+    def predict_links(self, head_ids, tail_ids):
+        s = self.calc_score(head_ids, tail_ids)
+        lo, hi = s.min(), s.max()
+        return ((s - lo) / (hi - lo) > self.milestone_score).int()
+
+    def get_final_embeddings(self, entity_ids):
+        return self.gat_embeddings()[entity_ids]
+
+    def forward(self, *input, device, mode):
+        self.device = device
+        if mode == "pre_training":
+            return self.calc_triplet_loss(*input)
+        if mode == "update_att":
+            return self.update_attention(*input)
+        if mode == "predict":
+            return self.predict_links(*input)
+        if mode == "fine_tuning":
+            return self.calculate_prediction_loss(*input)
+        return None   # unknown modes fall through silently, as in the reference (model.py:521-532)
+
+    def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
+        raise NotImplementedError("fine_tuning head (model.py:316-348) is a SURVEY 8f-1 'next' row")

@@ -1,0 +1,404 @@
+"""torch.autograd.Function wrappers over the C ABI (include/literalkg_hip.h).
+
+Every op launches on ``torch.cuda.current_stream()`` and REQUIRES device tensors: there is no CPU
+path here (the CPU restatement lives under ``oracle/`` and is test infrastructure only).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _native as N
+from .graph import KGStructure
+
+LEAKY_SLOPE = 0.01
+LN_EPS = 1e-5
+NORMALIZE_EPS = 1e-12
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "literalkg_amd ops run only on an MI355X device tensor (got a CPU tensor); there is no CPU "
+                "fallback -- move the model and its inputs to the GPU (model.to('cuda')).")
+
+
+def _f32_rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 2-D tensor with unit column stride (row stride arbitrary)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def _i64(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------- raw launches
+def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
+             x_row_offset: int = 0) -> torch.Tensor:
+    """out[i,:] = sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows described by rowptr
+    (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets a
+    row-range shard hand over only ITS rows of x while col keeps global ids."""
+    _need_gpu(x, val, rowptr, col)
+    x = _f32_rows(x)
+    d = x.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, d), dtype=torch.float32, device=x.device)
+    N.call("lkg_spmm_csr_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
+           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), _stream())
+    return out
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+         beta: float = 0.0, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = alpha * op(a) @ op(b) + beta * out (+ bias).  a, b: row-major 2-D fp32 (row stride free)."""
+    a, b = _f32_rows(a), _f32_rows(b)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    kb, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if k != kb:
+        raise ValueError(f"gemm: inner dimensions differ ({k} vs {kb})")
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("gemm: beta != 0 needs out")
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    N.call("lkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, float(alpha), N.ptr(a), _ld(a), N.ptr(b), _ld(b),
+           float(beta), N.ptr(out), _ld(out), N.ptr(bias), _stream())
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    x = _f32_rows(x)
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    N.call("lkg_colsum_f32", x.shape[0], x.shape[1], N.ptr(x), _ld(x), N.ptr(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- K1+K2 attention refresh
+@torch.no_grad()
+def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_logits: bool = False,
+                 row_lo: int = 0, row_hi: Optional[int] = None, out: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Attention values (CSR entry order) of head rows [row_lo, row_hi) -- model.py:430-471.
+    Returns (values float32[nnz], merged logits or None); rows outside the range are left untouched."""
+    _need_gpu(ent, relemb, g.rowptr)
+    ent, relemb = _f32_rows(ent), _f32_rows(relemb)
+    if ent.shape[1] != relemb.shape[1]:
+        raise ValueError("update_att adds entity and relation embeddings: embed_dim must equal relation_dim "
+                         "(model.py:441)")
+    row_hi = g.n if row_hi is None else row_hi
+    val = out if out is not None else torch.empty(g.nnz, dtype=torch.float32, device=ent.device)
+    logits = torch.empty(g.nnz, dtype=torch.float32, device=ent.device) if want_logits else None
+    N.call("lkg_edge_softmax_f32", row_hi - row_lo, row_lo, ent.shape[1], g.rowptr.data_ptr() + 4 * row_lo,
+           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
+           N.ptr(logits), _stream())
+    return val, logits
+
+
+def permute_values(val: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(val)
+    N.call("lkg_permute_f32", val.numel(), N.ptr(perm), N.ptr(val), N.ptr(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- K3/K4 aggregation
+class _Aggregate(Function):
+    """side = A @ ego over the CSR; backward A^T @ grad over the CSC (A carries no gradient,
+    model.py:261)."""
+
+    @staticmethod
+    def forward(ctx, ego, g: KGStructure, val, val_t):
+        _need_gpu(ego, val)
+        ctx.g = g
+        ctx.val_t = val_t
+        return spmm_raw(g.rowptr, g.col, val, ego, g.n)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = ctx.g
+        if g.t_rowptr is None:
+            raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
+        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n), None, None, None
+
+
+def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor) -> torch.Tensor:
+    return _Aggregate.apply(ego, g, val, val_t)
+
+
+# ----------------------------------------------------------------------------- dense layers on the MFMA GEMM
+class _MultiLinear(Function):
+    """y = sum_i x_i @ w_i^T + bias  (nn.Linear on a column-concatenated input without the cat:
+    gate.py:22-25; plain nn.Linear is the one-term case)."""
+
+    @staticmethod
+    def forward(ctx, bias, n_terms, *xw):
+        xs, ws = xw[:n_terms], xw[n_terms:]
+        _need_gpu(*xs, *ws)
+        y = None
+        for i, (x, w) in enumerate(zip(xs, ws)):
+            y = gemm(x, w, trans_b=True, beta=0.0 if i == 0 else 1.0, out=y, bias=bias if i == 0 else None)
+        ctx.save_for_backward(*xs, *ws)
+        ctx.n_terms = n_terms
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n_terms
+        saved = ctx.saved_tensors
+        xs, ws = saved[:n], saved[n:]
+        gy = _f32_rows(gy)
+        gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[0]) else None
+        gxs, gws = [], []
+        for i in range(n):
+            gxs.append(gemm(gy, ws[i]) if ctx.needs_input_grad[2 + i] else None)
+        for i in range(n):
+            gws.append(gemm(gy, xs[i], trans_a=True) if ctx.needs_input_grad[2 + n + i] else None)
+        return (gb, None, *gxs, *gws)
+
+
+def linear(x, w, b=None):
+    return _MultiLinear.apply(b, 1, x, w)
+
+
+def multi_linear(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], b=None):
+    return _MultiLinear.apply(b, len(xs), *xs, *ws)
+
+
+class _MatMul(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        gc = _f32_rows(gc)
+        ga = gemm(gc, b, trans_b=True) if ctx.needs_input_grad[0] else None
+        gb = gemm(a, gc, trans_a=True) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def matmul(a, b):
+    return _MatMul.apply(a, b)
+
+
+# ----------------------------------------------------------------------------- K5 epilogue
+class _ActLayerNorm(Function):
+    """y = LayerNorm(LeakyReLU(z)); yn = y / max(|y|_2, eps)  (model.py:111, 161, 305)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps):
+        _need_gpu(z, gamma, beta)
+        z = _f32_rows(z)
+        n, d = z.shape
+        y = torch.empty((n, d), dtype=torch.float32, device=z.device)
+        yn = torch.empty((n, d), dtype=torch.float32, device=z.device) if want_norm else None
+        mean = torch.empty(n, dtype=torch.float32, device=z.device)
+        rstd = torch.empty(n, dtype=torch.float32, device=z.device)
+        N.call("lkg_act_layernorm_fwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta),
+               float(eps), N.ptr(y), _ld(y), N.ptr(yn), _ld(yn) if yn is not None else 0, float(norm_eps),
+               N.ptr(mean), N.ptr(rstd), _stream())
+        ctx.save_for_backward(z, gamma, y, mean, rstd)
+        ctx.cfg = (slope, norm_eps)
+        ctx.set_materialize_grads(False)
+        if want_norm:
+            return y, yn
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, gyn):
+        z, gamma, y, mean, rstd = ctx.saved_tensors
+        slope, norm_eps = ctx.cfg
+        n, d = z.shape
+        if gy is None and gyn is None:
+            return None, None, None, None, None, None, None
+        gy = _f32_rows(gy) if gy is not None else None
+        gyn = _f32_rows(gyn) if gyn is not None else None
+        gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
+        gg = torch.zeros(d, dtype=torch.float32, device=z.device)
+        gb = torch.zeros(d, dtype=torch.float32, device=z.device)
+        N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
+               N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
+               _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
+               _stream())
+        return gz, gg, gb, None, None, None, None
+
+
+def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS):
+    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps)
+
+
+# ----------------------------------------------------------------------------- K6 gate blend
+class _GateBlend(Function):
+    @staticmethod
+    def forward(ctx, x, gpre, zpre):
+        _need_gpu(x, gpre, zpre)
+        x, gpre, zpre = _f32_rows(x), _f32_rows(gpre), _f32_rows(zpre)
+        n, d = x.shape
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        N.call("lkg_gate_blend_fwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
+               N.ptr(out), _ld(out), _stream())
+        ctx.save_for_backward(x, gpre, zpre)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, gpre, zpre = ctx.saved_tensors
+        go = _f32_rows(go)
+        n, d = x.shape
+        gx, gg, gz = (torch.empty((n, d), dtype=torch.float32, device=x.device) for _ in range(3))
+        N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
+               N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), _stream())
+        return gx, gg, gz
+
+
+def gate_blend(x, gpre, zpre):
+    return _GateBlend.apply(x, gpre, zpre)
+
+
+# ----------------------------------------------------------------------------- K8 TransE scoring
+class _TransELoss(Function):
+    """model_bce.py:329-368 on table rows."""
+
+    @staticmethod
+    def forward(ctx, emb, relemb, h, r, pt, nt, lam, keep):
+        _need_gpu(emb, relemb, h, r, pt, nt)
+        emb, relemb = _f32_rows(emb), _f32_rows(relemb)
+        if emb.shape[1] != relemb.shape[1]:
+            raise ValueError(f"TransE scoring needs entity-side width == relation_dim ({emb.shape[1]} vs "
+                             f"{relemb.shape[1]})")
+        h, r, pt, nt = _i64(h), _i64(r), _i64(pt), _i64(nt)
+        b = h.numel()
+        buf = torch.empty((4, b), dtype=torch.float32, device=emb.device)
+        loss = torch.empty((), dtype=torch.float32, device=emb.device)
+        N.call("lkg_transe_score_fwd_f32", b, emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(relemb), _ld(relemb),
+               N.ptr(h), N.ptr(r), N.ptr(pt), N.ptr(nt), N.ptr(buf[0]), N.ptr(buf[1]), N.ptr(buf[2]), N.ptr(buf[3]),
+               _stream())
+        N.call("lkg_loss_reduce_f32", b, N.ptr(buf[3]), N.ptr(buf[2]), float(lam), N.ptr(loss), _stream())
+        ctx.save_for_backward(emb, relemb, h, r, pt, nt, buf)
+        ctx.lam = lam
+        if keep is not None:
+            keep["pos"], keep["neg"] = buf[0], buf[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        emb, relemb, h, r, pt, nt, buf = ctx.saved_tensors
+        gl = gl.contiguous().float()
+        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        g_rel = torch.zeros_like(relemb, memory_format=torch.contiguous_format)
+        N.call("lkg_transe_score_bwd_f32", h.numel(), emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(relemb), _ld(relemb),
+               N.ptr(h), N.ptr(r), N.ptr(pt), N.ptr(nt), N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl),
+               N.ptr(g_emb), _ld(g_emb), N.ptr(g_rel), _ld(g_rel), _stream())
+        return g_emb, g_rel, None, None, None, None, None, None
+
+
+def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None):
+    return _TransELoss.apply(emb, relemb, h, r, pos_t, neg_t, lam, keep)
+
+
+# ----------------------------------------------------------------------------- K7+K8 TransR scoring
+def _grouped(mode, seg, max_len, a, b, out, m, n, k, trans_a, trans_b, beta, stride_b=0, stride_c=0):
+    N.call("lkg_grouped_gemm_f32", mode, seg.numel() - 1, N.ptr(seg), max_len, int(trans_a), int(trans_b), m, n, k,
+           1.0, N.ptr(a), _ld(a), N.ptr(b), b.stride(-2), stride_b, float(beta), N.ptr(out), out.stride(-2), stride_c,
+           _stream())
+
+
+class _TransRLoss(Function):
+    """model.py:364-428.  The batch is grouped by relation so W_r = gat_trans_M[r] is applied by ONE
+    grouped MFMA GEMM per operand; the B x C x D gather of the reference never exists."""
+
+    @staticmethod
+    def forward(ctx, emb, relemb, trans_m, h, r, pt, nt, lam, keep):
+        _need_gpu(emb, relemb, trans_m, h, r, pt, nt)
+        emb, relemb = _f32_rows(emb), _f32_rows(relemb)
+        trans_m = trans_m.contiguous()
+        n_rel, c, dout = trans_m.shape
+        if emb.shape[1] != c or relemb.shape[1] != dout:
+            raise ValueError("gat_trans_M shape does not match the embedding widths")
+        h, r, pt, nt = _i64(h), _i64(r), _i64(pt), _i64(nt)
+        b = h.numel()
+        dev = emb.device
+        perm = torch.empty(b, dtype=torch.int32, device=dev)
+        seg = torch.empty(n_rel + 1, dtype=torch.int32, device=dev)
+        N.call("lkg_group_by_key_i64", b, n_rel, N.ptr(r), N.ptr(perm), N.ptr(seg), _stream())
+        rs = torch.empty_like(r)
+        N.call("lkg_gather_i64", b, N.ptr(r), N.ptr(perm), N.ptr(rs), _stream())
+        x = torch.empty((3, b, c), dtype=torch.float32, device=dev)      # gathered rows, relation order
+        p = torch.empty((3, b, dout), dtype=torch.float32, device=dev)   # projected rows
+        for i, ids in enumerate((h, pt, nt)):
+            N.call("lkg_gather_rows_f32", b, c, N.ptr(emb), _ld(emb), N.ptr(ids), N.ptr(perm), N.ptr(x[i]), c,
+                   _stream())
+            _grouped(1, seg, b, x[i], trans_m, p[i], 0, dout, c, False, False, 0.0, stride_b=c * dout)
+        buf = torch.empty((4, b), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        N.call("lkg_dense_score_fwd_f32", b, dout, N.ptr(p[0]), N.ptr(p[1]), N.ptr(p[2]), dout, N.ptr(relemb),
+               _ld(relemb), N.ptr(rs), N.ptr(buf[0]), N.ptr(buf[1]), N.ptr(buf[2]), N.ptr(buf[3]), _stream())
+        N.call("lkg_loss_reduce_f32", b, N.ptr(buf[3]), N.ptr(buf[2]), float(lam), N.ptr(loss), _stream())
+        ctx.save_for_backward(emb, relemb, trans_m, h, pt, nt, rs, perm, seg, x, p, buf)
+        ctx.lam = lam
+        if keep is not None:   # scores back in the caller's triple order
+            inv = torch.empty_like(perm, dtype=torch.int64)
+            inv[perm.long()] = torch.arange(b, device=dev)
+            keep["pos"], keep["neg"] = buf[0][inv], buf[1][inv]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        emb, relemb, trans_m, h, pt, nt, rs, perm, seg, x, p, buf = ctx.saved_tensors
+        n_rel, c, dout = trans_m.shape
+        b = h.numel()
+        dev = emb.device
+        gl = gl.contiguous().float()
+        gp = torch.empty_like(p)
+        g_rel = torch.zeros_like(relemb, memory_format=torch.contiguous_format)
+        N.call("lkg_dense_score_bwd_f32", b, dout, N.ptr(p[0]), N.ptr(p[1]), N.ptr(p[2]), dout, N.ptr(relemb),
+               _ld(relemb), N.ptr(rs), N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl), N.ptr(gp[0]),
+               N.ptr(gp[1]), N.ptr(gp[2]), dout, N.ptr(g_rel), _ld(g_rel), _stream())
+        g_w = torch.empty_like(trans_m)
+        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        gx = torch.empty((b, c), dtype=torch.float32, device=dev)
+        for i, ids in enumerate((h, pt, nt)):
+            # g_W[r] (+)= X_r^T G_r
+            _grouped(2, seg, b, x[i], gp[i], g_w, c, dout, 0, True, False, 0.0 if i == 0 else 1.0,
+                     stride_c=c * dout)
+            # g_X = G W_r^T, scattered back to the table rows
+            _grouped(1, seg, b, gp[i], trans_m, gx, 0, c, dout, False, True, 0.0, stride_b=c * dout)
+            N.call("lkg_scatter_add_rows_f32", b, c, N.ptr(gx), c, N.ptr(ids), N.ptr(perm), N.ptr(g_emb),
+                   _ld(g_emb), _stream())
+        return g_emb, g_rel, g_w, None, None, None, None, None, None
+
+
+def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None):
+    return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep)
+
+
+# ----------------------------------------------------------------------------- f1 heads
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """table[ids] without autograd (inference heads, model.py:475-476)."""
+    _need_gpu(table, ids)
+    table, ids = _f32_rows(table), _i64(ids)
+    out = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    N.call("lkg_gather_rows_f32", ids.numel(), table.shape[1], N.ptr(table), _ld(table), N.ptr(ids), None, N.ptr(out),
+           table.shape[1], _stream())
+    return out

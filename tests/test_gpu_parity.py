@@ -1,0 +1,400 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
+generated from the reference.  Tolerances: integer indices bit-exact; fp32 values within 1e-4
+(BASELINE.json north_star), most checks far tighter.  Run with ``-m gpu`` on the MI355X box."""
+import json
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, golden_names, golden_params, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def L(gpu_device):
+    import __graft_entry__ as ge
+    ge.build()
+    import literalkg_amd
+    return literalkg_amd
+
+
+@pytest.fixture(scope="module")
+def ops(L):
+    from literalkg_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import literalkg_oracle
+    return literalkg_oracle
+
+
+def rand_graph(rng, n, e, n_rel=5, long_rows=()):
+    h = (n * rng.random(e) ** 1.7).astype(np.int64)
+    t = rng.integers(0, n, e)
+    r = rng.integers(0, n_rel, e)
+    for row, deg in long_rows:
+        h = np.concatenate([h, np.full(deg, row)])
+        t = np.concatenate([t, rng.choice(n, deg, replace=deg > n)])
+        r = np.concatenate([r, rng.integers(0, n_rel, deg)])
+    trip = np.unique(np.stack([h, r, t], 1), axis=0)
+    trip = trip[rng.permutation(len(trip))]
+    return trip[:, 0].copy(), trip[:, 2].copy(), trip[:, 1].copy()
+
+
+def coo_of(graph, val):
+    return torch.sparse_coo_tensor(graph.coo_indices().cpu(), val.cpu(), (graph.n, graph.n)).coalesce()
+
+
+# ----------------------------------------------------------------------------- K3/K4 SpMM
+@pytest.mark.parametrize("d", [4, 8, 30, 32, 64, 100, 128, 256, 300, 512, 1028])
+def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
+    rng = np.random.default_rng(d)
+    n = 700
+    h, t, r = rand_graph(rng, n, 6000, long_rows=[(3, 65), (10, 200), (500, 640)])
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    val = torch.rand(g.nnz, device=gpu_device)
+    x = torch.randn(n, d, device=gpu_device)
+    want = O.aggregate(coo_of(g, val), x.cpu())
+    got = ops.spmm_raw(g.rowptr, g.col, val, x, n)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    # rows without entries are exact zeros
+    empty = (g.rowptr[1:] == g.rowptr[:-1]).cpu()
+    assert empty.any() and float(got.cpu()[empty].abs().max()) == 0.0
+    # transpose pass == A^T @ grad
+    gt = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), x, n)
+    torch.testing.assert_close(gt.cpu(), torch.matmul(coo_of(g, val).t(), x.cpu()), rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_strided_views_and_autograd(L, ops, O, gpu_device):
+    rng = np.random.default_rng(5)
+    n, d = 300, 64
+    h, t, r = rand_graph(rng, n, 2500)
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    val = torch.rand(g.nnz, device=gpu_device)
+    big = torch.randn(n, 3 * d, device=gpu_device)
+    x = big[:, d:2 * d]                       # column slice: row stride 3d
+    outbuf = torch.zeros(n, 2 * d, device=gpu_device)
+    ops.spmm_raw(g.rowptr, g.col, val, x, n, out=outbuf[:, d:])
+    want = O.aggregate(coo_of(g, val), x.cpu())
+    torch.testing.assert_close(outbuf[:, d:].cpu(), want, rtol=1e-5, atol=1e-5)
+    assert float(outbuf[:, :d].abs().max()) == 0.0
+    from literalkg_amd.model import AttentionCSR
+    att = AttentionCSR(g, val)
+    xg = x.clone().requires_grad_(True)
+    w = torch.randn(n, d, device=gpu_device)
+    (att.aggregate(xg) * w).sum().backward()
+    xc = x.cpu().clone().requires_grad_(True)
+    (O.aggregate(coo_of(g, val), xc) * w.cpu()).sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_empty_and_ragged(L, ops, gpu_device):
+    n = 9
+    g = L.KGStructure.from_triples(n, np.array([8, 8, 8]), np.array([0, 4, 8]), np.array([0, 0, 1]), device=gpu_device)
+    x = torch.arange(n * 4, dtype=torch.float32, device=gpu_device).reshape(n, 4)
+    val = torch.tensor([1.0, 2.0, 3.0], device=gpu_device)
+    got = ops.spmm_raw(g.rowptr, g.col, val, x, n).cpu()
+    assert float(got[:8].abs().max()) == 0.0
+    torch.testing.assert_close(got[8], (x[0] + 2 * x[4] + 3 * x[8]).cpu())
+    g0 = L.KGStructure.from_triples(n, np.zeros(0, np.int64), np.zeros(0, np.int64), None, device=gpu_device)
+    z = ops.spmm_raw(g0.rowptr, g0.col, torch.zeros(0, device=gpu_device), x, n)
+    assert float(z.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- K1+K2 attention
+@pytest.mark.parametrize("name", golden_names("attention_"))
+def test_attention_refresh_golden(L, ops, gpu_device, name):
+    gd = load_golden(name)
+    n = int(gd["n"])
+    g = L.KGStructure.from_triples(n, gd["h"], gd["t"], gd["r"], device=gpu_device)
+    ent, rel = torch.from_numpy(gd["entity"]).to(gpu_device), torch.from_numpy(gd["relation"]).to(gpu_device)
+    val, logits = ops.edge_softmax(g, ent, rel, want_logits=True)
+    assert np.array_equal(g.coo_indices().cpu().numpy(), gd["a_indices"])          # int64, bit-exact
+    np.testing.assert_allclose(val.cpu().numpy(), gd["a_values"], rtol=1e-5, atol=1e-7)
+    # merged logits: sum the reference's per-edge logits over duplicate (h,t) pairs
+    key = gd["h"] * n + gd["t"]
+    uk, inv = np.unique(key, return_inverse=True)
+    merged = np.zeros(len(uk))
+    np.add.at(merged, inv, gd["logits"].astype(np.float64))
+    np.testing.assert_allclose(logits.cpu().numpy(), merged, rtol=1e-5, atol=1e-6)
+    assert g.has_dups == (len(uk) < len(key))
+
+
+@pytest.mark.parametrize("d", [8, 64, 100, 128, 256, 512])
+def test_attention_refresh_random(L, ops, O, gpu_device, d):
+    rng = np.random.default_rng(100 + d)
+    n = 500
+    h, t, r = rand_graph(rng, n, 5000, n_rel=6, long_rows=[(7, 70), (9, 333)])
+    # force duplicate (h,t) pairs, some tripled
+    extra = np.stack([h[:40], (r[:40] + 1) % 6, t[:40]], 1)
+    extra2 = np.stack([h[:10], (r[:10] + 2) % 6, t[:10]], 1)
+    trip = np.unique(np.concatenate([np.stack([h, r, t], 1), extra, extra2]), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    ent = torch.randn(n, d) * 0.5
+    rel = torch.randn(6, d) * 0.5
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    assert g.has_dups
+    val, _ = ops.edge_softmax(g, ent.to(gpu_device), rel.to(gpu_device))
+    rows, cols, want = O.attention_refresh_explicit(n, ent, rel, *(torch.from_numpy(a) for a in (h, t, r)))
+    assert torch.equal(g.coo_indices().cpu(), torch.stack([rows, cols]))
+    torch.testing.assert_close(val.cpu(), want, rtol=1e-4, atol=1e-6)
+    ref = O.attention_refresh(n, ent, rel, *(torch.from_numpy(a) for a in (h, t, r))).coalesce()
+    torch.testing.assert_close(val.cpu(), ref.values(), rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (130, 70, 33), (257, 300, 558), (1000, 256, 256), (64, 128, 16),
+                                   (5, 260, 1030)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm(ops, gpu_device, m, n, k, ta, tb):
+    gen = torch.Generator().manual_seed(m * 7 + n * 3 + k + ta * 2 + tb)
+    a = torch.randn((k, m) if ta else (m, k), generator=gen)
+    b = torch.randn((n, k) if tb else (k, n), generator=gen)
+    bias = torch.randn(n, generator=gen)
+    c0 = torch.randn(m, n, generator=gen)
+    want = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    got = ops.gemm(a.to(gpu_device), b.to(gpu_device), bool(ta), bool(tb))
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-4 * max(1, k) ** 0.5)
+    got2 = ops.gemm(a.to(gpu_device), b.to(gpu_device), bool(ta), bool(tb), alpha=0.5, beta=2.0,
+                    out=c0.clone().to(gpu_device), bias=bias.to(gpu_device))
+    torch.testing.assert_close(got2.cpu().double(), 0.5 * want + 2.0 * c0.double() + bias.double(), rtol=1e-5,
+                               atol=1e-4 * max(1, k) ** 0.5)
+
+
+def test_gemm_split_k_and_slices(ops, gpu_device):
+    gen = torch.Generator().manual_seed(3)
+    gy = torch.randn(40000, 96, generator=gen)
+    x = torch.randn(40000, 200, generator=gen)[:, 8:136]           # column slice, ld 200
+    got = ops.gemm(gy.to(gpu_device), x.to(gpu_device), trans_a=True)      # weight-gradient shape, K = 40000
+    want = gy.double().t() @ x.double()
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-4, atol=2e-2)
+    w = torch.randn(64, 558, generator=gen)
+    xx = torch.randn(300, 256, generator=gen)
+    got = ops.gemm(xx.to(gpu_device), w.to(gpu_device)[:, 2:258], trans_b=True)   # unaligned column panel
+    torch.testing.assert_close(got.cpu().double(), xx.double() @ w[:, 2:258].double().t(), rtol=1e-5, atol=1e-3)
+
+
+# ----------------------------------------------------------------------------- K5 / K6 epilogues
+@pytest.mark.parametrize("d", [8, 30, 64, 256, 300, 1024])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_act_layernorm(ops, gpu_device, d, with_norm):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(d)
+    n = 257
+    z = torch.randn(n, d, generator=gen)
+    gamma, beta = torch.randn(d, generator=gen), torch.randn(d, generator=gen)
+    wy, wn = torch.randn(n, d, generator=gen), torch.randn(n, d, generator=gen)
+
+    def ref(z, gamma, beta):
+        y = F.layer_norm(F.leaky_relu(z, 0.01), (d,), gamma, beta, 1e-5)
+        return y, F.normalize(y, p=2.0, dim=1)
+    zc, gc, bc = (t.clone().requires_grad_(True) for t in (z, gamma, beta))
+    y, yn = ref(zc, gc, bc)
+    ((y * wy).sum() + ((yn * wn).sum() if with_norm else 0)).backward()
+    zg, gg, bg = (t.clone().to(gpu_device).requires_grad_(True) for t in (z, gamma, beta))
+    y2, yn2 = ops.act_layernorm(zg, gg, bg, want_norm=with_norm)
+    loss = (y2 * wy.to(gpu_device)).sum()
+    if with_norm:
+        loss = loss + (yn2 * wn.to(gpu_device)).sum()
+        torch.testing.assert_close(yn2.cpu(), yn.detach(), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    torch.testing.assert_close(y2.cpu(), y.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(zg.grad.cpu(), zc.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gg.grad.cpu(), gc.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bg.grad.cpu(), bc.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_gates_match_oracle(L, O, gpu_device):
+    gen = torch.Generator().manual_seed(9)
+    n, d = 333, 48
+    x = torch.randn(n, d, generator=gen) * 0.3
+    num, txt = torch.rand(n, 2, generator=gen), torch.randn(n, 300, generator=gen)
+    for mod, lits, prefix in ((L.GateMul(d, 2, 300), (num, txt), "gm."), (L.Gate(d, 300), (txt,), "g1.")):
+        with torch.no_grad():
+            mod.gate_bias.normal_(0, 0.1)
+        p = {prefix + k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+        xc = x.clone().requires_grad_(True)
+        want = O.gate_mul(p, prefix, xc, *lits) if len(lits) == 2 else O.gate_single(p, prefix, xc, *lits)
+        w = torch.randn(n, d, generator=gen)
+        (want * w).sum().backward()
+        mod = mod.to(gpu_device)
+        xg = x.clone().to(gpu_device).requires_grad_(True)
+        got = mod(xg, *(l.to(gpu_device) for l in lits))
+        (got * w.to(gpu_device)).sum().backward()
+        torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(xg.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-5)
+        for k, v in mod.named_parameters():
+            torch.testing.assert_close(v.grad.cpu(), p[prefix + k].grad, rtol=1e-4, atol=1e-4, msg=k)
+
+
+# ----------------------------------------------------------------------------- K7/K8 scoring
+@pytest.mark.parametrize("form", ["transe", "transr"])
+@pytest.mark.parametrize("c,dout,b", [(32, 32, 17), (96, 64, 300), (200, 128, 1000)])
+def test_triple_losses(ops, O, gpu_device, form, c, dout, b):
+    from types import SimpleNamespace
+    if form == "transe":
+        dout = c
+    gen = torch.Generator().manual_seed(c + b)
+    n, n_rel = 400, 7
+    gat = torch.randn(n, c, generator=gen) * 0.4
+    p = {"relation_embed.weight": torch.randn(n_rel, dout, generator=gen) * 0.4,
+         "gat_trans_M": torch.randn(n_rel, c, dout, generator=gen) * 0.2}
+    ids = [torch.randint(0, n, (b,), generator=gen) for _ in range(3)]
+    r = torch.randint(0, n_rel - 1, (b,), generator=gen)          # relation n_rel-1 never occurs: empty group
+    cfg = SimpleNamespace(kg_l2loss_lambda=1e-3)
+    gc = gat.clone().requires_grad_(True)
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    fn = O.triple_loss_transe if form == "transe" else O.triple_loss_transr
+    sc = O.triple_scores_transe if form == "transe" else O.triple_scores_transr
+    want = fn(pc, cfg, gc, ids[0], r, ids[1], ids[2])
+    (want * 1.7).backward()
+    pos_w, neg_w, _ = sc(p, gat, ids[0], r, ids[1], ids[2])
+    gg = gat.clone().to(gpu_device).requires_grad_(True)
+    pg = {k: v.clone().to(gpu_device).requires_grad_(True) for k, v in p.items()}
+    dev_ids = [i.to(gpu_device) for i in ids]
+    keep = {}
+    if form == "transe":
+        got = ops.transe_loss(gg, pg["relation_embed.weight"], dev_ids[0], r.to(gpu_device), dev_ids[1], dev_ids[2],
+                              1e-3, keep)
+    else:
+        got = ops.transr_loss(gg, pg["relation_embed.weight"], pg["gat_trans_M"], dev_ids[0], r.to(gpu_device),
+                              dev_ids[1], dev_ids[2], 1e-3, keep)
+    (got * 1.7).backward()
+    torch.testing.assert_close(keep["pos"].cpu(), pos_w, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(keep["neg"].cpu(), neg_w, rtol=1e-4, atol=1e-4)
+    assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    torch.testing.assert_close(gg.grad.cpu(), gc.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(pg["relation_embed.weight"].grad.cpu(), pc["relation_embed.weight"].grad, rtol=1e-3,
+                               atol=1e-6)
+    if form == "transr":
+        torch.testing.assert_close(pg["gat_trans_M"].grad.cpu(), pc["gat_trans_M"].grad, rtol=1e-3, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- whole module vs golden
+def _build_model(L, gd, device, scoring):
+    cfg = golden_cfg(gd)
+    n, n_rel = int(gd["n"]), int(gd["n_rel"])
+    a_in = torch.sparse_coo_tensor(torch.from_numpy(gd["a_indices"]), torch.from_numpy(gd["a_values"]), (n, n)).coalesce()
+    num = torch.from_numpy(gd["num"]) if "num" in gd else None
+    txt = torch.from_numpy(gd["txt"]) if "txt" in gd else None
+    m = L.LiteralKG(cfg, n, n_rel, a_in, num, txt, scoring=scoring)
+    params = golden_params(gd)
+    own = set(m.state_dict().keys())
+    missing = m.load_state_dict({k: v for k, v in params.items() if k in own}, strict=False)
+    assert missing.missing_keys == ["A_in"], missing
+    return m.to(device).eval()
+
+
+@pytest.mark.parametrize("name", golden_names("encoder_") + golden_names("transe_"))
+def test_module_matches_reference_fixture(L, gpu_device, name):
+    gd = load_golden(name)
+    form = str(gd["form"])
+    m = _build_model(L, gd, gpu_device, form)
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    np.testing.assert_allclose(m.gat_embed.detach().cpu().numpy(), gd["gat"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(m.last_scores["pos"].cpu().numpy(), gd["pos"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(m.last_scores["neg"].cpu().numpy(), gd["neg"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(float(loss), float(gd["loss"]), rtol=1e-5)
+    loss.backward()
+    grads = {k: v.grad for k, v in m.named_parameters() if v.grad is not None}
+    n_checked = 0
+    for k, want in gd.items():
+        if k.startswith("g/"):
+            assert k[2:] in grads, k
+            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+            n_checked += 1
+    assert n_checked >= 4
+    if form == "transr":
+        hid, tid = torch.from_numpy(gd["score_heads"]).to(gpu_device), torch.from_numpy(gd["score_tails"]).to(gpu_device)
+        with torch.no_grad():
+            np.testing.assert_allclose(m.calc_score(hid, tid).cpu().numpy(), gd["score"], rtol=TOL, atol=TOL)
+            assert np.array_equal(m(hid, tid, device=gpu_device, mode="predict").cpu().numpy(), gd["predict"])
+
+
+def test_update_att_through_module(L, O, gpu_device):
+    gd = load_golden("encoder_gcn_l1")
+    m = _build_model(L, gd, gpu_device, "transr")
+    h, t, r = (torch.from_numpy(gd[k]).to(gpu_device) for k in "htr")
+    n_rel = int(gd["n_rel"])
+    out = m(h, t, r, list(range(n_rel)), device=gpu_device, mode="update_att")
+    assert out is None
+    p = golden_params(gd)
+    want = O.attention_refresh(int(gd["n"]), p["entity_embed.weight"], p["relation_embed.weight"],
+                               *(torch.from_numpy(gd[k]) for k in "htr")).coalesce()
+    a = m.A_in.data
+    assert a.is_sparse and a.dtype == torch.float32 and a.indices().dtype == torch.int64
+    assert torch.equal(a.indices().cpu(), want.indices())
+    torch.testing.assert_close(a.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
+    # training consumes the refreshed values; state_dict round-trips the sparse parameter
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    want_loss = O.pre_training_loss(p, golden_cfg(gd), want, *(torch.from_numpy(gd[k]) for k in ("bh", "br", "bp", "bn")))
+    np.testing.assert_allclose(float(loss), float(want_loss), rtol=1e-5)
+    sd = m.state_dict()
+    assert sd["A_in"].is_sparse and sd["A_in"]._nnz() == want._nnz()
+    # only a subset of relations: the reference silently drops the other edges (model.py:451)
+    m(h, t, r, [0, 2], device=gpu_device, mode="update_att")
+    keep = (r == 0) | (r == 2)
+    want2 = O.attention_refresh(int(gd["n"]), p["entity_embed.weight"], p["relation_embed.weight"],
+                                h[keep].cpu(), t[keep].cpu(), r[keep].cpu(), [0, 2]).coalesce()
+    assert torch.equal(m.A_in.data.indices().cpu(), want2.indices())
+    torch.testing.assert_close(m.A_in.data.values().cpu(), want2.values(), rtol=1e-5, atol=1e-7)
+    assert m(h, device=gpu_device, mode="no_such_mode") is None
+
+
+def test_training_mode_dropout_statistics(L, gpu_device):
+    gd = load_golden("encoder_gcn_l1")
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.aggregator_layers[0].dropout = 0.5
+    m.train()
+    torch.manual_seed(0)
+    e = m.gat_embeddings()
+    layer_out = e[:, 16:]                                    # normalised copy of the dropped-out layer output
+    frac = float((layer_out == 0).float().mean())
+    assert 0.4 < frac < 0.6
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(L, ops, gpu_device):
+    """BASELINE config shape (1M entities / 10M edges / D=256): size-independent properties."""
+    from literalkg_amd.synth import make_kg, xavier_table
+    n, e, d = 1_000_000, 10_000_000, 256
+    h, t, r = make_kg(n, e)
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    assert g.nnz < e and g.has_dups                                     # forced duplicate pairs were merged
+    rp, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == g.nnz and np.all(np.diff(rp) >= 0)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    key = rows.astype(np.int64) * n + col
+    assert np.all(np.diff(key) > 0)                                     # sorted by (h,t), no duplicate pair
+    assert np.array_equal(np.unique(h * n + t), key)                    # exactly the distinct input pairs
+    ent = xavier_table(n, d, gpu_device)
+    rel = xavier_table(16, d, gpu_device, seed=7)
+    val, _ = ops.edge_softmax(g, ent, rel)
+    ones = torch.ones(n, 8, device=gpu_device)
+    rs = ops.spmm_raw(g.rowptr, g.col, val, ones, n)[:, 0]
+    nonempty = torch.from_numpy(np.diff(rp) > 0).to(gpu_device)
+    assert float((rs[nonempty] - 1).abs().max()) < 1e-5                 # softmax rows sum to one
+    assert float(rs[~nonempty].abs().max()) == 0.0
+    x1, x2 = torch.randn(n, d, device=gpu_device), torch.randn(n, d, device=gpu_device)
+    a = ops.spmm_raw(g.rowptr, g.col, val, x1, n)
+    b = ops.spmm_raw(g.rowptr, g.col, val, x2, n)
+    ab = ops.spmm_raw(g.rowptr, g.col, val, x1 + 2 * x2, n)
+    assert float((ab - (a + 2 * b)).abs().max()) < 1e-4                 # linearity
+    # <A x, y> == <x, A^T y>  (forward kernel against the transpose kernel)
+    y = torch.randn(n, d, device=gpu_device)
+    aty = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), y, n)
+    lhs, rhs = float((a.double() * y.double()).sum()), float((x1.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-2
+    # spot-check 200 rows against a direct evaluation
+    pick = np.random.default_rng(0).choice(np.flatnonzero(np.diff(rp) > 0), 200, replace=False)
+    for i in pick[:200]:
+        sl = slice(rp[i], rp[i + 1])
+        want = (val[sl][:, None] * x1[torch.from_numpy(col[sl]).long().to(gpu_device)]).sum(0)
+        assert float((a[i] - want).abs().max()) < 1e-4

@@ -1,0 +1,121 @@
+"""CPU: the C-ABI library loads, exports every symbol include/literalkg_hip.h declares, and its HOST
+entry points (KG structure build) are bit-exact against a numpy restatement.  No device calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as ge
+    ge.build()
+    from literalkg_amd import _native
+    return _native
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "literalkg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lkg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = native.load()
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/literalkg_hip.h but not exported"
+    assert sorted(native.PROTOTYPES) == names        # the ctypes table mirrors the header exactly
+    assert lib.lkg_version() >= 100
+
+
+def test_error_convention(native):
+    h = np.array([0, 5], np.int64)
+    t = np.array([1, 1], np.int64)
+    out = [np.zeros(8, np.int32) for _ in range(4)] + [np.zeros(8, np.int64), np.zeros(1, np.int64)]
+    with pytest.raises(native.LkgError, match="outside"):
+        native.call("lkg_csr_build", 3, 2, native.ptr(h), native.ptr(t), None, *[native.ptr(o) for o in out])
+    with pytest.raises(native.LkgError, match="null"):
+        native.call("lkg_csr_build", 3, 2, None, native.ptr(t), None, *[native.ptr(o) for o in out])
+    with pytest.raises(native.LkgError, match="d must be positive"):
+        native.call("lkg_spmm_csr_f32", 4, 0, None, None, None, None, 0, None, 0, None)
+
+
+def numpy_csr(n, h, t, r):
+    """Restatement of coalesce()'s index work (model.py:468-470): sort by (h,t), merge equal pairs."""
+    order = np.lexsort((np.arange(len(h)), t, h))
+    hs, ts = h[order], t[order]
+    new = np.r_[True, (hs[1:] != hs[:-1]) | (ts[1:] != ts[:-1])] if len(h) else np.zeros(0, bool)
+    eptr = np.r_[np.flatnonzero(new), len(h)]
+    col = ts[new]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.add.at(rowptr, hs[new] + 1, 1)
+    return np.cumsum(rowptr), col, eptr, r[order], order
+
+
+@pytest.mark.parametrize("seed,n,e", [(0, 50, 400), (1, 1000, 20000), (2, 7, 0), (3, 300, 3000)])
+def test_csr_build_bit_exact(native, seed, n, e):
+    from literalkg_amd import KGStructure
+    rng = np.random.default_rng(seed)
+    h = (n * rng.random(e) ** 2).astype(np.int64)
+    t = rng.integers(0, max(n // 3, 1), e)                  # many duplicate (h,t) pairs
+    r = rng.integers(0, 4, e)
+    g = KGStructure.from_triples(n, h, t, r)
+    rowptr, col, eptr, rel, order = numpy_csr(n, h, t, r)
+    assert g.nnz == len(col) and g.n_raw == e
+    assert np.array_equal(g.host("rowptr"), rowptr)
+    assert np.array_equal(g.host("col"), col)
+    assert np.array_equal(g.host("rel"), rel)
+    assert np.array_equal(g.order, order)
+    if g.nnz != e:
+        assert np.array_equal(g.host("eptr"), eptr)
+    else:
+        assert g.host("eptr") is None
+    # transpose: same entries, sorted by (t, h); t_perm points back at the CSR entry
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    tp = g.host("t_perm")
+    assert np.array_equal(np.sort(tp), np.arange(g.nnz))
+    assert np.array_equal(g.host("t_col"), rows[tp])
+    tr = np.repeat(np.arange(n), np.diff(g.host("t_rowptr")))
+    assert np.array_equal(tr, col[tp])
+    assert np.all(np.diff(tr.astype(np.int64) * n + rows[tp]) > 0)
+    assert g.coo_indices().dtype == torch.int64
+    assert np.array_equal(g.coo_indices().numpy(), np.stack([rows, col]))
+
+
+@pytest.mark.parametrize("name", ["attention_toy5", "attention_rand300", "attention_testslice"])
+def test_structure_equals_reference_coalesced_indices(native, name):
+    from literalkg_amd import KGStructure
+    gd = load_golden(name)
+    g = KGStructure.from_triples(int(gd["n"]), gd["h"], gd["t"], gd["r"])
+    assert np.array_equal(g.coo_indices().numpy(), gd["a_indices"])       # bit-exact vs torch coalesce
+    assert g.has_dups == (g.nnz < len(gd["h"]))
+
+
+def test_row_partition_balances_entries(native):
+    from literalkg_amd import KGStructure
+    rng = np.random.default_rng(4)
+    n, e = 5000, 60000
+    h = (n * rng.random(e) ** 3).astype(np.int64)
+    g = KGStructure.from_triples(n, h, rng.integers(0, n, e), None)
+    rp = g.host("rowptr")
+    for parts in (1, 2, 3, 8):
+        cuts = g.row_cuts(parts)
+        assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts) >= 0)
+        loads = np.diff(rp[cuts])
+        assert loads.sum() == g.nnz
+        assert loads.max() - g.nnz / parts <= np.diff(rp).max()       # within one row of perfect balance
+
+
+def test_from_coo_keeps_value_order(native):
+    from literalkg_amd import KGStructure
+    gd = load_golden("encoder_gcn_l1")
+    n = int(gd["n"])
+    a = torch.sparse_coo_tensor(torch.from_numpy(gd["a_indices"]), torch.from_numpy(gd["a_values"]), (n, n)).coalesce()
+    g = KGStructure.from_coo(a)
+    assert np.array_equal(g.coo_indices().numpy(), gd["a_indices"]) and not g.has_dups
