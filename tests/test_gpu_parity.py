@@ -42,6 +42,7 @@ def rand_graph(rng, n, e, n_rel=5, long_rows=()):
         t = np.concatenate([t, rng.choice(n, deg, replace=deg > n)])
         r = np.concatenate([r, rng.integers(0, n_rel, deg)])
     trip = np.unique(np.stack([h, r, t], 1), axis=0)
+    trip = trip[(trip[:, 0] % 37) != 5]                     # rows 5, 42, 79, ... stay empty
     trip = trip[rng.permutation(len(trip))]
     return trip[:, 0].copy(), trip[:, 2].copy(), trip[:, 1].copy()
 
@@ -55,7 +56,7 @@ def coo_of(graph, val):
 def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
     rng = np.random.default_rng(d)
     n = 700
-    h, t, r = rand_graph(rng, n, 6000, long_rows=[(3, 65), (10, 200), (500, 640)])
+    h, t, r = rand_graph(rng, n, 6000, long_rows=[(3, 65), (10, 200), (501, 640)])
     g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
     val = torch.rand(g.nnz, device=gpu_device)
     x = torch.randn(n, d, device=gpu_device)
