@@ -1,0 +1,84 @@
+"""CPU, world_size 2, gloo: the row-range sharding + gradient all-reduce choreography of
+literalkg_amd/sharding.py.  The product default backend is the HIP SpMM (GPU only); here the test
+injects a torch-CPU SpMM with the same call signature so the N>1 logic is rehearsed without a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def cpu_spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0):
+    rp = rowptr.long()
+    lo, hi = int(rp[0]), int(rp[-1])
+    rows = torch.repeat_interleave(torch.arange(n_rows), rp[1:] - rp[:-1])
+    res = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
+    res.index_add_(0, rows, val[lo:hi, None] * x[col[lo:hi].long() - x_row_offset])
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def cpu_permute(val, perm):
+    return val[perm.long()]
+
+
+def _worker(rank, world, port, n, d, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from literalkg_amd import KGStructure
+        from literalkg_amd.sharding import ShardedAggregation
+        rng = np.random.default_rng(11)                       # same graph on every rank
+        e = 6000
+        h = (n * rng.random(e) ** 2.0).astype(np.int64)
+        t = rng.integers(0, n, e)
+        r = rng.integers(0, 3, e)
+        full = KGStructure.from_triples(n, h, t, r)
+        val_full = torch.from_numpy(rng.random(full.nnz).astype(np.float32))
+        cuts = full.row_cuts(world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        keep = (h >= lo) & (h < hi)
+        mine = KGStructure.from_triples(n, h[keep], t[keep], r[keep])
+        rp = full.host("rowptr")
+        val = val_full[rp[lo]:rp[hi]]                         # the shard's entries are a contiguous slice
+        assert mine.nnz == val.numel()
+        shard = ShardedAggregation(mine, val, lo, hi, spmm=cpu_spmm, permute=cpu_permute, n_chunks=3)
+        x = torch.from_numpy(np.random.default_rng(5).standard_normal((n, d)).astype(np.float32))
+        gfull = torch.from_numpy(np.random.default_rng(6).standard_normal((n, d)).astype(np.float32))
+        side = shard.forward(x)
+        grad = shard.backward(gfull[lo:hi].contiguous())
+        a = torch.sparse_coo_tensor(full.coo_indices(), val_full, (n, n)).coalesce()
+        want_side = torch.matmul(a, x)[lo:hi]
+        want_grad = torch.matmul(a.t(), gfull)
+        ok = torch.allclose(side, want_side, rtol=1e-5, atol=1e-5) and \
+            torch.allclose(grad, want_grad, rtol=1e-5, atol=1e-4)
+        q.put((rank, bool(ok), lo, hi, float((grad - want_grad).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_sharded_forward_backward():
+    import __graft_entry__ as ge
+    ge.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 500, 12, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] for r in res), res
+    assert res[0][2] == 0 and res[0][3] == res[1][2] and res[1][3] == 500     # contiguous row ranges
