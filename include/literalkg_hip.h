@@ -75,10 +75,14 @@ int lkg_row_partition(int64_t n_rows, const int32_t *rowptr, int32_t n_parts, in
  * K3/K4  neighbour aggregation  out[i,:] = sum_{j in row i} val[j] * x[col[j],:]
  * Replaces torch.matmul(A_in, ego) (model.py:106); called with the CSC arrays
  * it is the backward A^T grad.  Rows without entries are written as zeros.
- * rowptr is int32[n_rows+1] holding offsets into col/val; x has >= max(col)+1 rows. */
+ * rowptr is int32[n_rows+1] holding offsets into col/val; x has >= max(col)+1 rows.
+ * long_rows (nullable, device int32[n_long]): the rows (relative to rowptr) holding more than
+ * long_thresh entries; each of them gets a whole workgroup instead of one wave so that a skewed
+ * degree distribution does not leave one wave as the tail of the launch.  The list must contain
+ * exactly the rows with > long_thresh entries (KGStructure builds it on the host).             */
 int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                      const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
-                     void *stream);
+                     const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
 
 /* K1+K2  attention refresh, fused: per stored entry
  *     v = sum over its raw edges e of  sum_d ent[t,d] * tanh(ent[h,d] + relemb[rel[e],d])

@@ -48,35 +48,23 @@ __device__ __forceinline__ void reduce_subgroups(V &a) {
     if constexpr (LPE <= 8) vec_ops<V>::template xor_add<8>(a);
 }
 
-// V: float4 (16-byte chunks) or float.  LPE: lanes per edge.  CPL: chunks per lane.  U: edges in flight.
-// FULL: nchunk == LPE * CPL, i.e. no lane ever falls outside the row (drops the per-load guard).
+// Accumulate entries [start, end) of one row into acc.  `wave_i` / `n_waves`: this wave takes the 64-entry
+// chunks wave_i, wave_i + n_waves, ... (n_waves == 1 for the wave-per-row kernel).
 //
 // The edge loop is branch-free on purpose: a predicated gather (`ok ? load : 0`) makes hipcc emit a
 // branch per load and, at the joins, a conservative s_waitcnt vmcnt(0) that serialises the U gathers.
 // Instead the tail slots of the last group re-read the row's last valid source row (an L1 hit) with
 // weight 0.
 template <typename V, int LPE, int CPL, int U, bool FULL>
-__global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
-                                                        const int *__restrict__ rowptr,
-                                                        const int *__restrict__ col,
-                                                        const float *__restrict__ val,
-                                                        const float *__restrict__ x, long ldx,
-                                                        float *__restrict__ out, long ldo) {
+__device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int end, int wave_i, int n_waves,
+                                                   int lane, int nchunk, const int *__restrict__ col,
+                                                   const float *__restrict__ val, const float *__restrict__ x,
+                                                   long ldx) {
     using ops = vec_ops<V>;
     constexpr int EPW = 64 / LPE;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
-    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
     const int sub = lane / LPE;
     const int sl = lane % LPE;
-
-    V acc[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
-
-    for (int base = start; base < end; base += 64) {
+    for (int base = start + 64 * wave_i; base < end; base += 64 * n_waves) {
         const int cnt = min(64, end - base);
         const int last = cnt - 1;
         // one coalesced fetch of up to 64 (col, val) pairs; lanes past the row end copy its last entry
@@ -117,36 +105,103 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                 for (int i = 0; i < CPL; ++i) ops::fma(acc[i], vv[u], xv[u][i]);
         }
     }
+}
+
+// V: float4 (16-byte chunks) or float.  LPE: lanes per edge.  CPL: chunks per lane.  U: edges in flight.
+// FULL: nchunk == LPE * CPL, i.e. no lane ever falls outside the row (drops the per-load guard).
+// Rows longer than long_thresh (> 0) are left to spmm_long_rows_kernel.
+template <typename V, int LPE, int CPL, int U, bool FULL>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
+                                                        const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col,
+                                                        const float *__restrict__ val,
+                                                        const float *__restrict__ x, long ldx,
+                                                        float *__restrict__ out, long ldo, int long_thresh) {
+    using ops = vec_ops<V>;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    if (long_thresh > 0 && end - start > long_thresh) return;
+    V acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
+    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, 0, 1, lane, nchunk, col, val, x, ldx);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
-    if (sub == 0) {
+    if (lane / LPE == 0) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const int chunk = sl + i * LPE;
+            const int chunk = lane % LPE + i * LPE;
             if (FULL || chunk < nchunk) dst[chunk] = acc[i];
+        }
+    }
+}
+
+// Rows longer than the threshold: one workgroup of LONG_WAVES waves per row, the waves take interleaved
+// 64-entry chunks, partial sums meet in LDS and are added in a fixed order (deterministic, no atomics).
+constexpr int LONG_WAVES = 8;
+template <typename V, int LPE, int CPL, int U, bool FULL>
+__global__ __launch_bounds__(64 * LONG_WAVES) void spmm_long_rows_kernel(int nchunk, const int *__restrict__ long_rows,
+                                                                          const int *__restrict__ rowptr,
+                                                                          const int *__restrict__ col,
+                                                                          const float *__restrict__ val,
+                                                                          const float *__restrict__ x, long ldx,
+                                                                          float *__restrict__ out, long ldo) {
+    using ops = vec_ops<V>;
+    __shared__ V part[LONG_WAVES][CPL][LPE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = long_rows[blockIdx.x];
+    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    V acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
+    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, w, LONG_WAVES, lane, nchunk, col, val, x, ldx);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
+    if (lane < LPE)
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) part[w][i][lane] = acc[i];
+    __syncthreads();
+    if (w == 0 && lane < LPE) {
+        V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            V s = part[0][i][lane];
+            for (int k = 1; k < LONG_WAVES; ++k) ops::fma(s, 1.f, part[k][i][lane]);
+            const int chunk = lane + i * LPE;
+            if (FULL || chunk < nchunk) dst[chunk] = s;
         }
     }
 }
 
 template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
-           int64_t ldx, float *out, int64_t ldo, hipStream_t s) {
+           int64_t ldx, float *out, int64_t ldo, const int *long_rows, int n_long, int long_thresh, hipStream_t s) {
     const int rows_per_block = 4;
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+    if (n_long > 0)   // longest first: they would otherwise be the tail of the launch
+        hipLaunchKernelGGL((spmm_long_rows_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)n_long),
+                           dim3(64 * LONG_WAVES), 0, s, nchunk, long_rows, rowptr, col, val, x, (long)ldx, out,
+                           (long)ldo);
     hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows,
-                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo);
+                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, n_long > 0 ? long_thresh : 0);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
 
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
-             int64_t ldx, float *out, int64_t ldo, hipStream_t s) {
+             int64_t ldx, float *out, int64_t ldo, const int *long_rows, int n_long, int long_thresh, hipStream_t s) {
 #define LKG_GO(LPE, CPL, U)                                                                              \
     return (nchunk == LPE * CPL)                                                                         \
-               ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, s)     \
-               : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, s)
+               ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, long_rows,  \
+                                              n_long, long_thresh, s)                                    \
+               : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, long_rows, \
+                                               n_long, long_thresh, s)
     if (nchunk <= 8) LKG_GO(8, 1, 4);
     if (nchunk <= 16) LKG_GO(16, 1, 4);
     if (nchunk <= 32) LKG_GO(32, 1, 4);
@@ -161,11 +216,13 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
 
 extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                                 const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
-                                void *stream) {
+                                const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
                 (long long)ldo, d);
+    LKG_REQUIRE(n_long >= 0 && (n_long == 0 || (long_rows && long_thresh >= 64)),
+                "lkg_spmm_csr_f32: long-row list needs a pointer and a threshold >= 64");
     if (n_rows == 0) return LKG_OK;
     LKG_REQUIRE(rowptr && x && out, "lkg_spmm_csr_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -174,8 +231,10 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     const int block_cols = 256 * width;   // columns one launch covers (CPL <= 4)
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
-        int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, s)
-                     : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo, s);
+        int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, long_rows, n_long,
+                                        long_thresh, s)
+                     : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo, long_rows, n_long,
+                                       long_thresh, s);
         if (rc != LKG_OK) return rc;
     }
     return LKG_OK;

@@ -13,10 +13,15 @@ Layout (E_raw raw triples, nnz <= E_raw stored entries, N entities):
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 import torch
 
 from . import _native as N
+
+
+LONG_ROW_THRESHOLD = 256   # rows above this get a whole workgroup in the SpMM (lkg_spmm_csr_f32)
 
 
 class KGStructure:
@@ -29,6 +34,7 @@ class KGStructure:
         self.order = None           # int64 host: sorted raw edge k is input edge order[k]
         self.device = torch.device("cpu")
         self._coo = None
+        self._long = {}
 
     # ------------------------------------------------------------------ build
     @classmethod
@@ -87,7 +93,19 @@ class KGStructure:
             self.t_rowptr = self.t_col = self.t_perm = None
         self.device = device
         self._coo = None
+        self._long = {}
         return self
+
+    def long_rows(self, transposed: bool = False, lo: int = 0, hi: Optional[int] = None):
+        """Device int32 list of the rows in [lo, hi) (relative to lo) with more than LONG_ROW_THRESHOLD
+        entries, for the CSR (transposed=False) or the CSC; None when there are none."""
+        hi = self.n if hi is None else hi
+        key = (transposed, lo, hi)
+        if key not in self._long:
+            rp = self._host["t_rowptr" if transposed else "rowptr"]
+            rows = np.flatnonzero(np.diff(rp[lo:hi + 1]) > LONG_ROW_THRESHOLD).astype(np.int32)
+            self._long[key] = torch.from_numpy(rows).to(self.device) if len(rows) else None
+        return self._long[key]
 
     # ------------------------------------------------------------------ views
     @property

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 
 from . import _native as N
-from .graph import KGStructure
+from .graph import KGStructure, LONG_ROW_THRESHOLD
 
 LEAKY_SLOPE = 0.01
 LN_EPS = 1e-5
@@ -53,7 +53,7 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
-             x_row_offset: int = 0) -> torch.Tensor:
+             x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows described by rowptr
     (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets a
     row-range shard hand over only ITS rows of x while col keeps global ids."""
@@ -63,7 +63,8 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
     if out is None:
         out = torch.empty((n_rows, d), dtype=torch.float32, device=x.device)
     N.call("lkg_spmm_csr_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
-           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), _stream())
+           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(long_rows),
+           0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
     return out
 
 
@@ -128,14 +129,14 @@ class _Aggregate(Function):
         _need_gpu(ego, val)
         ctx.g = g
         ctx.val_t = val_t
-        return spmm_raw(g.rowptr, g.col, val, ego, g.n)
+        return spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False))
 
     @staticmethod
     def backward(ctx, grad):
         g = ctx.g
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
-        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n), None, None, None
+        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True)), None, None, None
 
 
 def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor) -> torch.Tensor:

@@ -43,7 +43,8 @@ class ShardedAggregation:
     def forward(self, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """side rows [lo, hi) = A[lo:hi, :] @ table   (table: full N x D replica)"""
         g = self.graph
-        return self.spmm(g.rowptr[self.lo:self.hi + 1], g.col, self.val, table, self.hi - self.lo, out=out)
+        return self.spmm(g.rowptr[self.lo:self.hi + 1], g.col, self.val, table, self.hi - self.lo, out=out,
+                         long_rows=g.long_rows(False, self.lo, self.hi))
 
     def backward(self, grad_rows: torch.Tensor, out: Optional[torch.Tensor] = None, reduce: bool = True
                  ) -> torch.Tensor:
@@ -57,7 +58,7 @@ class ShardedAggregation:
         multi = reduce and dist.is_initialized() and dist.get_world_size(self.group) > 1
         for a, b in self.chunks:
             self.spmm(g.t_rowptr[a:b + 1], g.t_col, self.val_t, grad_rows, b - a, out=out[a:b],
-                      x_row_offset=self.lo)
+                      x_row_offset=self.lo, long_rows=g.long_rows(True, a, b))
             if multi:
                 works.append(dist.all_reduce(out[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:

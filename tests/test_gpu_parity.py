@@ -63,6 +63,10 @@ def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
     want = O.aggregate(coo_of(g, val), x.cpu())
     got = ops.spmm_raw(g.rowptr, g.col, val, x, n)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    # the long-row workgroup path (row 501 holds > 256 entries) gives the same result
+    assert g.long_rows(False) is not None and 501 in g.long_rows(False).tolist()
+    got_l = ops.spmm_raw(g.rowptr, g.col, val, x, n, long_rows=g.long_rows(False))
+    torch.testing.assert_close(got_l.cpu(), want, rtol=1e-5, atol=1e-5)
     # rows without entries are exact zeros
     empty = (g.rowptr[1:] == g.rowptr[:-1]).cpu()
     assert empty.any() and float(got.cpu()[empty].abs().max()) == 0.0

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of lkg_spmm_csr_f32 on the BASELINE graph shapes (GPU box only; not part of the tests).
+   python tools/spmm_micro.py [--dim 256] [--skew zipf]"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+ge.build()
+import literalkg_amd as L
+from literalkg_amd import ops
+from literalkg_amd.synth import make_kg, xavier_table
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dim", type=int, default=256)
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--e", type=int, default=10_000_000)
+ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+for skew in ("zipf", "uniform"):
+    h, t, r = make_kg(args.n, args.e, skew)
+    g = L.KGStructure.from_triples(args.n, h, t, r, device=dev)
+    d = args.dim
+    x = xavier_table(args.n, d, dev)
+    val = torch.rand(g.nnz, device=dev)
+    val_t = ops.permute_values(val, g.t_perm)
+    by = g.nnz * (4 * d + 8) + args.n * 4 * d + 4 * (args.n + 1)
+    def timeit(fn):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ms = np.array([a.elapsed_time(b) for a, b in ev])
+        return np.median(ms), ms.min()
+    out = torch.empty((args.n, d), device=dev)
+    for name, fn in [
+        ("fwd wave-per-row      ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out)),
+        ("fwd + long-row blocks ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
+        ("bwd wave-per-row      ", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out)),
+        ("bwd + long-row blocks ", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out, long_rows=g.long_rows(True))),
+    ]:
+        med, mn = timeit(fn)
+        print(f"{skew:8s} D={d} {name} median {med:.3f} ms  min {mn:.3f} ms  -> {by/med/1e6:.0f} GB/s algorithmic "
+              f"({by/med/1e6/8000:.3f} of 8 TB/s)  long rows: {0 if g.long_rows(False) is None else g.long_rows(False).numel()}")
+    # plain copy reference for this box: read+write 2 x table
+    y = torch.empty_like(x)
+    med, _ = timeit(lambda: y.copy_(x))
+    print(f"         torch copy of the {x.numel()*4/1e9:.2f} GB table: {med:.3f} ms -> {2*x.numel()*4/med/1e6:.0f} GB/s")
