@@ -36,6 +36,20 @@ def algorithmic_bytes(nnz, n_out_rows, d):
     return nnz * (4 * d + 8) + n_out_rows * 4 * d + 4 * (n_out_rows + 1)
 
 
+def pmc_traffic(by):
+    """HBM bytes per forward launch from the newest committed rocprofv3 --pmc summary (tools/pmc_traffic.py;
+    counters cannot be read from inside the process).  Used only when it was taken on this workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1]))
+    tr = rec.get("traffic_bytes_fwd")
+    if tr is None or abs(tr - by) > 0.25 * by:      # different shape: not comparable
+        return None, None
+    return tr, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(g, val, n, d, seed):
     """The oracle (the ATen ops the reference dispatches: sparse COO matmul forward, its autograd
     transpose product backward) timed on this box's host cores on the SAME graph and attention values:
@@ -165,6 +179,7 @@ def main():
     by_bwd = algorithmic_bytes(g.nnz, n_glob, d)
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(by) if world == 1 else (None, None)
         out = {
             "metric": "kg_edges_aggregated_per_sec",
             "value": 2 * total_entries * args.steps / elapsed,
@@ -184,7 +199,8 @@ def main():
                 "host_graph_build_s": round(t_build, 2),
             },
             "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel (forward launch)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
                          "bwd_launch_ms": float(bwd_ms.mean()),
                          "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if world == 1 else None},

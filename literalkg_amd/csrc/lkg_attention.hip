@@ -15,43 +15,65 @@
 
 namespace {
 
+// tanh for the per-edge logit.  The ocml tanhf costs ~40 VALU instructions and made this kernel
+// VALU-bound (4 per lane per edge); this form is ~15: an odd series below 0.25 (truncation < 2e-9 relative)
+// and 1 - 2 / (exp(2|x|) + 1) above, on v_exp_f32 / v_rcp_f32.  Absolute error <= 2e-7 over the real line.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float ax = fminf(fabsf(x), 10.f);
+    const float x2 = x * x;
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float e = __expf(2.f * ax);
+    const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
+    return ax < 0.25f ? poly : big;
+}
+
 template <typename V>
 struct dot_ops;
 template <>
 struct dot_ops<float4> {
     static __device__ __forceinline__ float tanh_dot(const float4 &t, const float4 &h, const float4 &r) {
-        return t.x * tanhf(h.x + r.x) + t.y * tanhf(h.y + r.y) + t.z * tanhf(h.z + r.z) + t.w * tanhf(h.w + r.w);
+        return t.x * tanh_fast(h.x + r.x) + t.y * tanh_fast(h.y + r.y) + t.z * tanh_fast(h.z + r.z) +
+               t.w * tanh_fast(h.w + r.w);
     }
     static __device__ __forceinline__ float4 zero() { return f4_zero(); }
 };
 template <>
 struct dot_ops<float> {
     static __device__ __forceinline__ float tanh_dot(const float &t, const float &h, const float &r) {
-        return t * tanhf(h + r);
+        return t * tanh_fast(h + r);
     }
     static __device__ __forceinline__ float zero() { return 0.f; }
 };
 
-template <typename V, int LPE, int CPL, int U, bool DUPS>
-__global__ __launch_bounds__(256) void edge_softmax_kernel(int n_rows, long row_offset, int nchunk,
-                                                            const int *__restrict__ rowptr,
-                                                            const int *__restrict__ col,
-                                                            const int *__restrict__ eptr,
-                                                            const int *__restrict__ rel,
-                                                            const float *__restrict__ ent, long ld_ent,
-                                                            const float *__restrict__ relemb, long ld_rel,
-                                                            float *__restrict__ val_out,
-                                                            float *__restrict__ logits_out) {
+constexpr int LONG_WAVES = 8;
+
+// TEAM = 1: one wave per head row.  TEAM = LONG_WAVES: one workgroup per (long) row taken from long_rows;
+// the waves take interleaved 64-entry chunks and meet in LDS for the softmax statistics.
+template <typename V, int LPE, int CPL, int U, bool DUPS, int TEAM>
+__global__ __launch_bounds__(TEAM == 1 ? 256 : 64 * TEAM) void edge_softmax_kernel(
+    int n_rows, long row_offset, int nchunk, const int *__restrict__ rowptr, const int *__restrict__ col,
+    const int *__restrict__ eptr, const int *__restrict__ rel, const float *__restrict__ ent, long ld_ent,
+    const float *__restrict__ relemb, long ld_rel, float *__restrict__ val_out, float *__restrict__ logits_out,
+    const int *__restrict__ long_rows, int long_thresh) {
     using ops = dot_ops<V>;
     constexpr int EPW = 64 / LPE;
+    __shared__ float red[TEAM == 1 ? 1 : TEAM];
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
+    const int w = threadIdx.x >> 6;
+    int row;
+    if constexpr (TEAM == 1) {
+        row = blockIdx.x * (blockDim.x >> 6) + w;
+        if (row >= n_rows) return;
+    } else {
+        row = long_rows[blockIdx.x];
+    }
     const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
     const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
     if (start >= end) return;
+    if (TEAM == 1 && long_thresh > 0 && end - start > long_thresh) return;
     const int sub = lane / LPE;
     const int sl = lane % LPE;
+    const int wave_i = TEAM == 1 ? 0 : w;
 
     // head embedding chunk(s) of this lane
     V hv[CPL];
@@ -65,7 +87,7 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(int n_rows, long row_
 #pragma unroll
     for (int i = 0; i < CPL; ++i) live[i] = (sl + i * LPE) < nchunk;
 
-    for (int base = start; base < end; base += 64) {
+    for (int base = start + 64 * wave_i; base < end; base += 64 * TEAM) {
         const int cnt = min(64, end - base);
         const int last = cnt - 1;
         const int jl = base + min(lane, last);
@@ -129,52 +151,82 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(int n_rows, long row_
             }
         }
     }
-    // the logits were written by other lanes of this wave: make them visible before re-reading
+    // the logits were written by other lanes (TEAM > 1: other waves) of this workgroup: make them visible
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
+    if constexpr (TEAM > 1) __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+    const int tid = TEAM == 1 ? lane : (int)threadIdx.x;
+    constexpr int TS = 64 * TEAM;
     float m = -INFINITY;
-    for (int j = start + lane; j < end; j += 64) m = fmaxf(m, val_out[j]);
+    for (int j = start + tid; j < end; j += TS) m = fmaxf(m, val_out[j]);
     m = wave_max(m);
+    if constexpr (TEAM > 1) {
+        if (lane == 0) red[w] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int i = 1; i < TEAM; ++i) m = fmaxf(m, red[i]);
+        __syncthreads();
+    }
     float s = 0.f;
-    for (int j = start + lane; j < end; j += 64) s += expf(val_out[j] - m);
+    for (int j = start + tid; j < end; j += TS) s += expf(val_out[j] - m);
     s = wave_sum(s);
-    for (int j = start + lane; j < end; j += 64) val_out[j] = expf(val_out[j] - m) / s;
+    if constexpr (TEAM > 1) {
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        s = red[0];
+#pragma unroll
+        for (int i = 1; i < TEAM; ++i) s += red[i];
+    }
+    for (int j = start + tid; j < end; j += TS) val_out[j] = expf(val_out[j] - m) / s;
 }
 
-template <typename V, int LPE, int CPL, int U>
-int launch(bool dups, int64_t n_rows, int64_t row_offset, int nchunk, const int *rowptr, const int *col,
-           const int *eptr, const int *rel, const float *ent, int64_t ld_ent, const float *relemb, int64_t ld_rel,
-           float *val_out, float *logits_out, hipStream_t s) {
-    const int64_t blocks = (n_rows + 3) / 4;
-    if (dups)
-        hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, true>), dim3((unsigned)blocks), dim3(256), 0, s,
-                           (int)n_rows, (long)row_offset, nchunk, rowptr, col, eptr, rel, ent, (long)ld_ent, relemb,
-                           (long)ld_rel, val_out, logits_out);
-    else
-        hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, false>), dim3((unsigned)blocks), dim3(256), 0, s,
-                           (int)n_rows, (long)row_offset, nchunk, rowptr, col, eptr, rel, ent, (long)ld_ent, relemb,
-                           (long)ld_rel, val_out, logits_out);
+struct EsArgs {
+    int64_t n_rows, row_offset;
+    int nchunk;
+    const int *rowptr, *col, *eptr, *rel;
+    const float *ent;
+    int64_t ld_ent;
+    const float *relemb;
+    int64_t ld_rel;
+    float *val_out, *logits_out;
+    const int *long_rows;
+    int n_long, long_thresh;
+};
+
+template <typename V, int LPE, int CPL, int U, bool DUPS>
+int launch2(const EsArgs &a, hipStream_t s) {
+    const int64_t blocks = (a.n_rows + 3) / 4;
+    const int thresh = a.n_long > 0 ? a.long_thresh : 0;
+    if (a.n_long > 0)
+        hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, DUPS, LONG_WAVES>), dim3((unsigned)a.n_long),
+                           dim3(64 * LONG_WAVES), 0, s, (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col,
+                           a.eptr, a.rel, a.ent, (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out, a.logits_out,
+                           a.long_rows, thresh);
+    hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, DUPS, 1>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col, a.eptr, a.rel, a.ent,
+                       (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out, a.logits_out, a.long_rows, thresh);
     LKG_CHECK_LAUNCH("lkg_edge_softmax_f32");
     return LKG_OK;
 }
 
+template <typename V, int LPE, int CPL, int U>
+int launch(const EsArgs &a, hipStream_t s) {
+    return a.eptr ? launch2<V, LPE, CPL, U, true>(a, s) : launch2<V, LPE, CPL, U, false>(a, s);
+}
+
 template <typename V>
-int dispatch(bool dups, int64_t n_rows, int64_t row_offset, int nchunk, const int *rowptr, const int *col,
-             const int *eptr, const int *rel, const float *ent, int64_t ld_ent, const float *relemb,
-             int64_t ld_rel, float *val_out, float *logits_out, hipStream_t s) {
-#define LKG_GO(LPE, CPL, U)                                                                                 \
-    return launch<V, LPE, CPL, U>(dups, n_rows, row_offset, nchunk, rowptr, col, eptr, rel, ent, ld_ent, relemb, \
-                                  ld_rel, val_out, logits_out, s)
-    if (nchunk <= 8) LKG_GO(8, 1, 4);
-    if (nchunk <= 16) LKG_GO(16, 1, 4);
-    if (nchunk <= 32) LKG_GO(32, 1, 4);
-    if (nchunk <= 64) LKG_GO(64, 1, 4);
-    if (nchunk <= 128) LKG_GO(64, 2, 2);
-    if (nchunk <= 192) LKG_GO(64, 3, 2);
-    if (nchunk <= 256) LKG_GO(64, 4, 1);
-#undef LKG_GO
+int dispatch(const EsArgs &a, hipStream_t s) {
+    const int nchunk = a.nchunk;
+    if (nchunk <= 8) return launch<V, 8, 1, 4>(a, s);
+    if (nchunk <= 16) return launch<V, 16, 1, 4>(a, s);
+    if (nchunk <= 32) return launch<V, 32, 1, 4>(a, s);
+    if (nchunk <= 64) return launch<V, 64, 1, 4>(a, s);
+    if (nchunk <= 128) return launch<V, 64, 2, 2>(a, s);
+    if (nchunk <= 192) return launch<V, 64, 3, 2>(a, s);
+    if (nchunk <= 256) return launch<V, 64, 4, 1>(a, s);
     lkg_set_error("lkg_edge_softmax_f32: embedding width of %d chunks exceeds the supported 256", nchunk);
     return LKG_ERR_UNSUPPORTED;
 }
@@ -184,15 +236,17 @@ int dispatch(bool dups, int64_t n_rows, int64_t row_offset, int nchunk, const in
 extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
                                     const int32_t *col, const int32_t *eptr, const int32_t *rel, const float *ent,
                                     int64_t ld_ent, const float *relemb, int64_t ld_rel, float *val_out,
-                                    float *logits_out, void *stream) {
+                                    float *logits_out, const int32_t *long_rows, int32_t n_long,
+                                    int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_offset >= 0, "lkg_edge_softmax_f32: bad row range");
     LKG_REQUIRE(d > 0 && ld_ent >= d && ld_rel >= d, "lkg_edge_softmax_f32: bad d/strides (d=%d)", d);
+    LKG_REQUIRE(n_long >= 0 && (n_long == 0 || (long_rows && long_thresh >= 64)),
+                "lkg_edge_softmax_f32: long-row list needs a pointer and a threshold >= 64");
     if (n_rows == 0) return LKG_OK;
     LKG_REQUIRE(rowptr && col && rel && ent && relemb && val_out, "lkg_edge_softmax_f32: null pointer");
     const bool vec = (d % 4 == 0) && (ld_ent % 4 == 0) && (ld_rel % 4 == 0) && lkg_aligned16(ent) && lkg_aligned16(relemb);
+    EsArgs a{n_rows, row_offset, vec ? d / 4 : d, rowptr, col, eptr, rel, ent, ld_ent, relemb, ld_rel,
+             val_out, logits_out, long_rows, n_long, long_thresh};
     hipStream_t s = (hipStream_t)stream;
-    return vec ? dispatch<float4>(eptr != nullptr, n_rows, row_offset, d / 4, rowptr, col, eptr, rel, ent, ld_ent,
-                                  relemb, ld_rel, val_out, logits_out, s)
-               : dispatch<float>(eptr != nullptr, n_rows, row_offset, d, rowptr, col, eptr, rel, ent, ld_ent, relemb,
-                                 ld_rel, val_out, logits_out, s);
+    return vec ? dispatch<float4>(a, s) : dispatch<float>(a, s);
 }

@@ -62,17 +62,17 @@ def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
     x = torch.randn(n, d, device=gpu_device)
     want = O.aggregate(coo_of(g, val), x.cpu())
     got = ops.spmm_raw(g.rowptr, g.col, val, x, n)
-    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=5e-5)   # 640-term fp32 sums, other order
     # the long-row workgroup path (row 501 holds > 256 entries) gives the same result
     assert g.long_rows(False) is not None and 501 in g.long_rows(False).tolist()
     got_l = ops.spmm_raw(g.rowptr, g.col, val, x, n, long_rows=g.long_rows(False))
-    torch.testing.assert_close(got_l.cpu(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got_l.cpu(), want, rtol=1e-5, atol=5e-5)
     # rows without entries are exact zeros
     empty = (g.rowptr[1:] == g.rowptr[:-1]).cpu()
     assert empty.any() and float(got.cpu()[empty].abs().max()) == 0.0
     # transpose pass == A^T @ grad
     gt = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), x, n)
-    torch.testing.assert_close(gt.cpu(), torch.matmul(coo_of(g, val).t(), x.cpu()), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gt.cpu(), torch.matmul(coo_of(g, val).t(), x.cpu()), rtol=1e-5, atol=5e-5)
 
 
 def test_spmm_strided_views_and_autograd(L, ops, O, gpu_device):

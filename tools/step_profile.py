@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Whole-path timing on the BASELINE shapes (GPU box): update_att, pre_training forward, backward.
+   python tools/step_profile.py --config c2|c3 [--agg gcn]"""
+import argparse, os, sys, time
+from types import SimpleNamespace
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+ge.build()
+import literalkg_amd as L
+from literalkg_amd.synth import make_kg, make_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c2")
+ap.add_argument("--agg", default="gcn")
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--scoring", default="transr")
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--e", type=int, default=10_000_000)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+cfgs = {
+    "c2": dict(embed_dim=128, relation_dim=128, conv_dim=128, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
+    "c3": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=2, use_num_lit=True, use_txt_lit=True),
+}
+base = dict(use_pretrain=0, device=dev, scale_gat_dim=None, use_residual=False, alpha=0.1, lamda=0.5,
+            aggregation_type=args.agg, mess_dropout=0.0, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
+            pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=300, milestone_score=0.5,
+            n_mlp_layers=2, mlp_hidden_dim=64)
+base.update(cfgs[args.config])
+cfg = SimpleNamespace(**base)
+n, e = args.n, args.e
+h, t, r = make_kg(n, e)
+num = torch.rand(n, 2, device=dev) if cfg.use_num_lit else None
+txt = torch.randn(n, 300, device=dev) if cfg.use_txt_lit else None
+model = L.LiteralKG(cfg, n, 16, None, num, txt, scoring=args.scoring).to(dev)
+model.eval()
+hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
+def sync_time(fn, iters=args.iters):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+t0 = time.perf_counter()
+model(hd, td, rd, list(range(16)), device=dev, mode="update_att"); torch.cuda.synchronize()
+print(f"first update_att incl. host CSR build: {(time.perf_counter()-t0)*1e3:.0f} ms")
+ua = sync_time(lambda: model(hd, td, rd, list(range(16)), device=dev, mode="update_att"))
+bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3))
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+def fwd():
+    return model(bh, br, bp, bn, device=dev, mode="pre_training")
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = fwd(); loss.backward()
+def step_opt():
+    step(); opt.step()
+with torch.no_grad():
+    f_ng = sync_time(fwd)
+f = sync_time(fwd)
+s = sync_time(step)
+so = sync_time(step_opt)
+L_ = cfg.n_conv_layers
+print(f"{args.config} {args.agg} {args.scoring}: update_att {ua:.2f} ms ({e/ua/1e6:.2f} G edges/s) | fwd(no grad) {f_ng:.2f} | fwd {f:.2f} | fwd+bwd {s:.2f} ms "
+      f"({e*L_/s/1e6:.2f} G edges/s) | +Adam {so:.2f} ms | mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
