@@ -155,6 +155,17 @@ int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int
                          const float *a, int64_t lda, const float *b, int64_t ldb, int64_t stride_b,
                          float beta, float *c, int64_t ldc, int64_t stride_c, void *stream);
 
+/* f1  fine-tuning head (model.py:316-348): dot-product BPR on table rows
+ *   pos_b = <e_h, e_p>, neg_b = <e_h, e_n>, reg_b = (|e_h|^2 + |e_p|^2 + |e_n|^2)/2,
+ *   rank_b = -logsigmoid(pos_b - neg_b);  loss via lkg_loss_reduce_f32 (lambda = fine_tuning_l2loss_lambda).
+ * Backward accumulates (atomic) into g_emb (zero-initialised by the caller).          */
+int lkg_dot_score_fwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb, const int64_t *h,
+                          const int64_t *pos_t, const int64_t *neg_t, float *pos, float *neg, float *reg,
+                          float *rank, void *stream);
+int lkg_dot_score_bwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb, const int64_t *h,
+                          const int64_t *pos_t, const int64_t *neg_t, const float *pos, const float *neg,
+                          float lambda, const float *g_loss, float *g_emb, int64_t ld_gemb, void *stream);
+
 /* Scores on already-projected rows (TransR form, model.py:413-426): same outputs
  * as lkg_transe_score_fwd_f32 but ph/pp/pn are dense batch x dim matrices.       */
 int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,
@@ -171,11 +182,15 @@ int lkg_dense_score_bwd_f32(int64_t batch, int32_t dim, const float *ph, const f
  *   a   = leaky_relu(z, slope)                    (z = Linear output, n x d)
  *   y   = layer_norm(a) * gamma + beta            (eps)
  *   yn  = y / max(|y|_2, norm_eps)                (nullable: the L2-normalised copy)
- * save_mean / save_rstd float[n] are kept for the backward.                       */
+ * save_mean / save_rstd float[n] are kept for the backward.
+ * drop_p > 0: message dropout (nn.Dropout, model.py:28/161) is applied to y BEFORE the normalised
+ *   copy is taken, y *= keep(seed, row*d + col) / (1 - drop_p) with a counter-based mask that the
+ *   backward regenerates from the same seed.                                           */
 int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *beta, float eps, float *y,
                               int64_t ldy, float *yn, int64_t ldyn, float norm_eps,
-                              float *save_mean, float *save_rstd, void *stream);
+                              float *save_mean, float *save_rstd, float drop_p, uint64_t seed,
+                              void *stream);
 
 /* Backward of the epilogue.  g_y and g_yn (nullable) are the upstream gradients of
  * the two outputs; writes g_z (n x d) and ACCUMULATES g_gamma / g_beta (atomic,
@@ -185,7 +200,7 @@ int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
-                              void *stream);
+                              float drop_p, uint64_t seed, void *stream);
 
 /* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
  *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)

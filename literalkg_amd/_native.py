@@ -5,7 +5,7 @@ import os
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liblkg_hip.so")
 _lib = None
 
-i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+i64, i32, f32, vp, u64 = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/literalkg_hip.h
 PROTOTYPES = {
@@ -29,9 +29,11 @@ PROTOTYPES = {
     "lkg_dense_score_fwd_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],
     "lkg_dense_score_bwd_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp, vp, vp, vp, i64, vp, i64,
                                 vp],
-    "lkg_act_layernorm_fwd_f32": [i64, i32, vp, i64, f32, vp, vp, f32, vp, i64, vp, i64, f32, vp, vp, vp],
+    "lkg_act_layernorm_fwd_f32": [i64, i32, vp, i64, f32, vp, vp, f32, vp, i64, vp, i64, f32, vp, vp, f32, u64, vp],
     "lkg_act_layernorm_bwd_f32": [i64, i32, vp, i64, f32, vp, vp, i64, vp, vp, vp, i64, vp, i64, f32, vp, i64, vp,
-                                  vp, vp],
+                                  vp, f32, u64, vp],
+    "lkg_dot_score_fwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lkg_dot_score_bwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp],
     "lkg_gate_blend_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gate_blend_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp],

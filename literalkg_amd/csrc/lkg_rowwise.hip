@@ -46,13 +46,26 @@ struct RowRegs {
     __device__ __forceinline__ bool live(int k, int d, int lane) const { return (lane + 64 * (k / W)) * W + (k % W) < d; }
 };
 
+// Counter-based dropout mask: keep(seed, element index) is a pure function (splitmix64 finaliser), so the
+// backward regenerates the mask instead of storing it.  torch's Philox stream cannot be reproduced from
+// outside ATen, so training-mode parity with the reference is statistical.
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
                                                           float slope, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
                                                           float *__restrict__ y, long ldy, float *__restrict__ yn,
                                                           long ldyn, float norm_eps, float *__restrict__ save_mean,
-                                                          float *__restrict__ save_rstd) {
+                                                          float *__restrict__ save_rstd, float drop_p,
+                                                          unsigned long long seed) {
     constexpr int K = CPL * W;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -77,9 +90,14 @@ __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const fl
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
     float nn = 0.f;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float o = (a.v[k] - mean) * rstd * g.v[k] + b.v[k];
+        float o = (a.v[k] - mean) * rstd * g.v[k] + b.v[k];
+        if (drop_p > 0.f) {
+            const int e = (lane + 64 * (k / W)) * W + (k % W);
+            o *= drop_scale(seed, (unsigned long long)row * d + e, drop_p, inv_keep);
+        }
         a.v[k] = o;
         nn += a.live(k, d, lane) ? o * o : 0.f;
     }
@@ -109,7 +127,8 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           const float *__restrict__ g_y, long ldgy,
                                                           const float *__restrict__ g_yn, long ldgyn, float norm_eps,
                                                           float *__restrict__ g_z, long ldgz,
-                                                          float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+                                                          float *__restrict__ g_gamma, float *__restrict__ g_beta,
+                                                          float drop_p, unsigned long long seed) {
     constexpr int K = CPL * W;
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -148,6 +167,14 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                 const float inv = 1.f / norm_eps;
 #pragma unroll
                 for (int k = 0; k < K; ++k) G.v[k] += gn.v[k] * inv;
+            }
+        }
+        if (drop_p > 0.f) {   // y (and g_y / g_yn) refer to the masked output: route G through the mask
+            const float inv_keep = 1.f / (1.f - drop_p);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int e = (lane + 64 * (k / W)) * W + (k % W);
+                G.v[k] *= drop_scale(seed, (unsigned long long)row * d + e, drop_p, inv_keep);
             }
         }
         const float mean = save_mean[row], rstd = save_rstd[row];
@@ -251,7 +278,8 @@ int pick_cpl(int d) {
 extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                                          const float *gamma, const float *beta, float eps, float *y, int64_t ldy,
                                          float *yn, int64_t ldyn, float norm_eps, float *save_mean, float *save_rstd,
-                                         void *stream) {
+                                         float drop_p, uint64_t seed, void *stream) {
+    LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_fwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldy >= d && (!yn || ldyn >= d), "lkg_act_layernorm_fwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
     LKG_REQUIRE(z && gamma && beta && y && save_mean && save_rstd, "lkg_act_layernorm_fwd_f32: null pointer");
@@ -260,7 +288,7 @@ extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, i
                      lkg_aligned16(y) && lkg_aligned16(gamma) && lkg_aligned16(beta) && (!yn || lkg_aligned16(yn));
     const dim3 grid((unsigned)((n + 3) / 4));
     LKG_ROW_DISPATCH(act_ln_fwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, beta, eps, y, (long)ldy, yn,
-                     (long)ldyn, norm_eps, save_mean, save_rstd);
+                     (long)ldyn, norm_eps, save_mean, save_rstd, drop_p, (unsigned long long)seed);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_fwd_f32");
     return LKG_OK;
 }
@@ -269,7 +297,8 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          const float *gamma, const float *y, int64_t ldy, const float *save_mean,
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
-                                         float *g_beta, void *stream) {
+                                         float *g_beta, float drop_p, uint64_t seed, void *stream) {
+    LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
     if (n == 0) return LKG_OK;
@@ -282,7 +311,8 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                      (!g_yn || (lkg_aligned16(g_yn) && lkg_aligned16(y)));
     const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 2048));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
-                     save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta);
+                     save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
+                     (unsigned long long)seed);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
     return LKG_OK;
 }

@@ -182,6 +182,56 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(long batch, int dim, con
     }
 }
 
+// f1 fine-tuning head: dot-product BPR (model.py:316-348)
+__global__ __launch_bounds__(256) void dot_fwd_kernel(long batch, int dim, const float *__restrict__ emb, long ld,
+                                                       const long *__restrict__ h, const long *__restrict__ pt,
+                                                       const long *__restrict__ nt, float *__restrict__ pos,
+                                                       float *__restrict__ neg, float *__restrict__ reg,
+                                                       float *__restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= batch) return;
+    const float *eh = emb + h[t] * ld, *ep = emb + pt[t] * ld, *en = emb + nt[t] * ld;
+    float sp = 0.f, sn = 0.f, qh = 0.f, qp = 0.f, qn = 0.f, zero = 0.f;
+    for (int k = lane; k < dim; k += 64) {
+        const float a = eh[k], b = ep[k], c = en[k];
+        sp = fmaf(a, b, sp);
+        sn = fmaf(a, c, sn);
+        qh = fmaf(a, a, qh);
+        qp = fmaf(b, b, qp);
+        qn = fmaf(c, c, qn);
+    }
+    six_reduce(sp, sn, qh, qp, qn, zero);
+    if (lane == 0) {
+        pos[t] = sp;
+        neg[t] = sn;
+        reg[t] = 0.5f * (qh + qp + qn);
+        rank[t] = neg_logsigmoid(sp - sn);
+    }
+}
+
+// d loss/d pos_b = -g * sigmoid(neg_b - pos_b) / B, d loss/d neg_b = +(same)
+__global__ __launch_bounds__(256) void dot_bwd_kernel(long batch, int dim, const float *__restrict__ emb, long ld,
+                                                       const long *__restrict__ h, const long *__restrict__ pt,
+                                                       const long *__restrict__ nt, const float *__restrict__ pos,
+                                                       const float *__restrict__ neg, float lambda,
+                                                       const float *__restrict__ g_loss, float *__restrict__ ge,
+                                                       long ldg) {
+    const int lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= batch) return;
+    const float g = g_loss[0], inv_b = 1.f / (float)batch;
+    const float dn = g * sigmoidf_(neg[t] - pos[t]) * inv_b, dp = -dn, lr = g * lambda * inv_b;
+    const float *eh = emb + h[t] * ld, *ep = emb + pt[t] * ld, *en = emb + nt[t] * ld;
+    float *gh = ge + h[t] * ldg, *gp = ge + pt[t] * ldg, *gn = ge + nt[t] * ldg;
+    for (int k = lane; k < dim; k += 64) {
+        const float a = eh[k], b = ep[k], c = en[k];
+        atomicAdd(gh + k, dp * b + dn * c + lr * a);
+        atomicAdd(gp + k, dp * a + lr * b);
+        atomicAdd(gn + k, dn * a + lr * c);
+    }
+}
+
 inline bool vec_ok(int dim, int64_t ld, int64_t ld_rel, const void *p0, const void *p1) {
     return dim % 4 == 0 && ld % 4 == 0 && ld_rel % 4 == 0 && lkg_aligned16(p0) && lkg_aligned16(p1);
 }
@@ -271,5 +321,31 @@ extern "C" int lkg_dense_score_bwd_f32(int64_t batch, int32_t dim, const float *
                        (long)batch, dim, ph, pp, pn, (long)ld, relemb, (long)ld_rel, nullptr, (const long *)r, nullptr,
                        nullptr, pos, neg, lambda, g_loss, g_ph, g_pp, g_pn, (long)ldg, g_rel, (long)ld_grel);
     LKG_CHECK_LAUNCH("lkg_dense_score_bwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_dot_score_fwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb, const int64_t *h,
+                                     const int64_t *pos_t, const int64_t *neg_t, float *pos, float *neg, float *reg,
+                                     float *rank, void *stream) {
+    LKG_REQUIRE(batch >= 0 && dim > 0 && ld_emb >= dim, "lkg_dot_score_fwd_f32: bad sizes");
+    if (batch == 0) return LKG_OK;
+    LKG_REQUIRE(emb && h && pos_t && neg_t && pos && neg && reg && rank, "lkg_dot_score_fwd_f32: null pointer");
+    hipLaunchKernelGGL(dot_fwd_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)batch, dim, emb, (long)ld_emb, (const long *)h, (const long *)pos_t, (const long *)neg_t,
+                       pos, neg, reg, rank);
+    LKG_CHECK_LAUNCH("lkg_dot_score_fwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_dot_score_bwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t ld_emb, const int64_t *h,
+                                     const int64_t *pos_t, const int64_t *neg_t, const float *pos, const float *neg,
+                                     float lambda, const float *g_loss, float *g_emb, int64_t ld_gemb, void *stream) {
+    LKG_REQUIRE(batch >= 0 && dim > 0 && ld_emb >= dim && ld_gemb >= dim, "lkg_dot_score_bwd_f32: bad sizes");
+    if (batch == 0) return LKG_OK;
+    LKG_REQUIRE(emb && h && pos_t && neg_t && pos && neg && g_loss && g_emb, "lkg_dot_score_bwd_f32: null pointer");
+    hipLaunchKernelGGL(dot_bwd_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)batch, dim, emb, (long)ld_emb, (const long *)h, (const long *)pos_t, (const long *)neg_t,
+                       pos, neg, lambda, g_loss, g_emb, (long)ld_gemb);
+    LKG_CHECK_LAUNCH("lkg_dot_score_bwd_f32");
     return LKG_OK;
 }

@@ -101,22 +101,18 @@ class Aggregator(nn.Module):
     def _lin(mod: nn.Linear, x):
         return ops.linear(x, mod.weight, mod.bias)
 
-    def _finish(self, z, extra_sum=None):
-        """LeakyReLU -> LayerNorm (-> dropout), and the L2-normalised copy when it can be fused."""
+    def _finish(self, z, extra_sum=None, slope=ops.LEAKY_SLOPE):
+        """LeakyReLU -> LayerNorm -> message dropout, plus the L2-normalised copy of the result that
+        gat_embeddings concatenates (model.py:161, 305) -- one fused kernel."""
         ln = self.layer_normalize
-        drop = self.training and self.dropout > 0
-        if extra_sum is None:
-            y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=not drop)
-        else:   # gin skip-sum: LN(act(z)) + earlier layers, then LN again (model.py:151-161)
+        p = float(self.dropout) if self.training else 0.0
+        if extra_sum is not None:   # gin skip-sum: LN(act(z)) + earlier layers, then LN again (model.py:151-161)
             inner, _ = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=False)
-            total = inner
+            z = inner
             for e in extra_sum:
-                total = total + e
-            # second LayerNorm has no activation in front: slope 1 makes LeakyReLU the identity
-            y, yn = ops.act_layernorm(total, ln.weight, ln.bias, want_norm=not drop, slope=1.0)
-        if drop:
-            y = F.dropout(y, self.dropout, True)
-            yn = None
+                z = z + e
+            slope = 1.0   # the second LayerNorm has no activation in front: slope 1 = identity
+        y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p)
         self.last_normalized = yn
         return y
 
@@ -143,13 +139,7 @@ class Aggregator(nn.Module):
             # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): do it here, then a
             # slope-1 epilogue for the LayerNorm
             z = F.leaky_relu(b, ops.LEAKY_SLOPE) + F.leaky_relu(s, ops.LEAKY_SLOPE)
-            ln = self.layer_normalize
-            drop = self.training and self.dropout > 0
-            y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=not drop, slope=1.0)
-            if drop:
-                y, yn = F.dropout(y, self.dropout, True), None
-            self.last_normalized = yn
-            return y
+            return self._finish(z, slope=1.0)
         # gin (model.py:131-158)
         if self.num_layers == 1:
             raise AttributeError("gin with n_mlp_layers == 1 cannot run in the reference either "
@@ -270,10 +260,7 @@ class LiteralKG(nn.Module):
         kept = [cur]
         for idx, layer in enumerate(self.aggregator_layers):
             cur = layer(cur, att, kept, self.lamda, self.alpha, idx + 1)
-            norm = layer.last_normalized
-            if norm is None:   # dropout active: the normalised copy is taken after the mask (model.py:304-305)
-                norm = F.normalize(cur, p=2.0, dim=1)
-            kept.append(norm)
+            kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused
         cat = torch.cat(kept, dim=1)
         if self.scale_gat_dim is not None:
             return F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
@@ -343,4 +330,6 @@ class LiteralKG(nn.Module):
         return None   # unknown modes fall through silently, as in the reference (model.py:521-532)
 
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
-        raise NotImplementedError("fine_tuning head (model.py:316-348) is a SURVEY 8f-1 'next' row")
+        """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
+        self.gat_embed = self.gat_embeddings()
+        return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda)

@@ -207,10 +207,11 @@ def matmul(a, b):
 
 # ----------------------------------------------------------------------------- K5 epilogue
 class _ActLayerNorm(Function):
-    """y = LayerNorm(LeakyReLU(z)); yn = y / max(|y|_2, eps)  (model.py:111, 161, 305)."""
+    """y = Dropout(LayerNorm(LeakyReLU(z))); yn = y / max(|y|_2, eps)  (model.py:111, 161, 305).
+    The dropout mask is counter-based (seed, element index) and regenerated in the backward."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps):
+    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed):
         _need_gpu(z, gamma, beta)
         z = _f32_rows(z)
         n, d = z.shape
@@ -220,9 +221,9 @@ class _ActLayerNorm(Function):
         rstd = torch.empty(n, dtype=torch.float32, device=z.device)
         N.call("lkg_act_layernorm_fwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta),
                float(eps), N.ptr(y), _ld(y), N.ptr(yn), _ld(yn) if yn is not None else 0, float(norm_eps),
-               N.ptr(mean), N.ptr(rstd), _stream())
+               N.ptr(mean), N.ptr(rstd), float(drop_p), int(seed), _stream())
         ctx.save_for_backward(z, gamma, y, mean, rstd)
-        ctx.cfg = (slope, norm_eps)
+        ctx.cfg = (slope, norm_eps, drop_p, seed)
         ctx.set_materialize_grads(False)
         if want_norm:
             return y, yn
@@ -231,10 +232,11 @@ class _ActLayerNorm(Function):
     @staticmethod
     def backward(ctx, gy, gyn):
         z, gamma, y, mean, rstd = ctx.saved_tensors
-        slope, norm_eps = ctx.cfg
+        slope, norm_eps, drop_p, seed = ctx.cfg
         n, d = z.shape
+        none = (None,) * 9
         if gy is None and gyn is None:
-            return None, None, None, None, None, None, None
+            return none
         gy = _f32_rows(gy) if gy is not None else None
         gyn = _f32_rows(gyn) if gyn is not None else None
         gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
@@ -243,12 +245,20 @@ class _ActLayerNorm(Function):
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               _stream())
-        return gz, gg, gb, None, None, None, None
+               float(drop_p), int(seed), _stream())
+        return (gz, gg, gb) + none[3:]
 
 
-def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS):
-    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps)
+def new_seed() -> int:
+    """63-bit seed drawn from torch's CPU generator (follows torch.manual_seed, no device sync)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS,
+                  drop_p: float = 0.0, seed: Optional[int] = None):
+    if drop_p > 0 and seed is None:
+        seed = new_seed()
+    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0)
 
 
 # ----------------------------------------------------------------------------- K6 gate blend
@@ -394,6 +404,39 @@ class _TransRLoss(Function):
 
 def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None):
     return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep)
+
+
+# ----------------------------------------------------------------------------- f1 fine-tuning head
+class _DotLoss(Function):
+    """model.py:316-348: dot-product BPR loss on table rows."""
+
+    @staticmethod
+    def forward(ctx, emb, h, pt, nt, lam):
+        _need_gpu(emb, h, pt, nt)
+        emb = _f32_rows(emb)
+        h, pt, nt = _i64(h), _i64(pt), _i64(nt)
+        b = h.numel()
+        buf = torch.empty((4, b), dtype=torch.float32, device=emb.device)
+        loss = torch.empty((), dtype=torch.float32, device=emb.device)
+        N.call("lkg_dot_score_fwd_f32", b, emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(h), N.ptr(pt), N.ptr(nt),
+               N.ptr(buf[0]), N.ptr(buf[1]), N.ptr(buf[2]), N.ptr(buf[3]), _stream())
+        N.call("lkg_loss_reduce_f32", b, N.ptr(buf[3]), N.ptr(buf[2]), float(lam), N.ptr(loss), _stream())
+        ctx.save_for_backward(emb, h, pt, nt, buf)
+        ctx.lam = lam
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        emb, h, pt, nt, buf = ctx.saved_tensors
+        gl = gl.contiguous().float()
+        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        N.call("lkg_dot_score_bwd_f32", h.numel(), emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(h), N.ptr(pt), N.ptr(nt),
+               N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl), N.ptr(g_emb), _ld(g_emb), _stream())
+        return g_emb, None, None, None, None
+
+
+def dot_loss(emb, h, pos_t, neg_t, lam):
+    return _DotLoss.apply(emb, h, pos_t, neg_t, lam)
 
 
 # ----------------------------------------------------------------------------- f1 heads

@@ -362,7 +362,54 @@ def test_training_mode_dropout_statistics(L, gpu_device):
     e = m.gat_embeddings()
     layer_out = e[:, 16:]                                    # normalised copy of the dropped-out layer output
     frac = float((layer_out == 0).float().mean())
-    assert 0.4 < frac < 0.6
+    assert 0.45 < frac < 0.55
+    torch.testing.assert_close(layer_out.norm(dim=1), torch.ones(layer_out.shape[0], device=gpu_device),
+                               rtol=1e-5, atol=1e-5)
+    torch.manual_seed(0)
+    e2 = m.gat_embeddings()
+    assert torch.equal(e, e2)                                # mask follows torch.manual_seed
+    e3 = m.gat_embeddings()
+    assert not torch.equal(e2, e3)                           # and changes from call to call
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_fused_dropout_forward_backward(ops, gpu_device, p):
+    """Dropout fused in the LN epilogue: the mask is a pure function of (seed, index), the kept fraction is
+    1-p, kept values are LN/(1-p), and the backward equals autograd through the same explicit mask."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(1)
+    n, d = 4000, 64
+    z = torch.randn(n, d, generator=gen).to(gpu_device)
+    gamma, beta = torch.randn(d, generator=gen).to(gpu_device), torch.randn(d, generator=gen).to(gpu_device)
+    wy, wn = torch.randn(n, d, generator=gen).to(gpu_device), torch.randn(n, d, generator=gen).to(gpu_device)
+    zg, gg, bg = (t.clone().requires_grad_(True) for t in (z, gamma, beta))
+    y, yn = ops.act_layernorm(zg, gg, bg, want_norm=True, drop_p=p, seed=1234)
+    ((y * wy).sum() + (yn * wn).sum()).backward()
+    full, _ = ops.act_layernorm(z, gamma, beta, want_norm=False)
+    mask = (y != 0).float()
+    assert abs(float(mask.mean()) - (1 - p)) < 0.01
+    torch.testing.assert_close(y, full * mask / (1 - p), rtol=1e-5, atol=1e-6)
+    y_again, _ = ops.act_layernorm(z, gamma, beta, want_norm=False, drop_p=p, seed=1234)
+    assert torch.equal(y.detach(), y_again)
+    # reference gradient: torch autograd through LN * explicit mask
+    zc, gc, bc = (t.clone().requires_grad_(True) for t in (z, gamma, beta))
+    yr = F.layer_norm(F.leaky_relu(zc, 0.01), (d,), gc, bc, 1e-5) * mask / (1 - p)
+    ((yr * wy).sum() + (F.normalize(yr, p=2.0, dim=1) * wn).sum()).backward()
+    torch.testing.assert_close(zg.grad, zc.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gg.grad, gc.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(bg.grad, bc.grad, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", golden_names("encoder_"))
+def test_fine_tuning_head_matches_reference_fixture(L, gpu_device, name):
+    gd = load_golden(name)
+    m = _build_model(L, gd, gpu_device, "transr")
+    bh, bp, bn = (torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "bp", "bn"))
+    loss = m(bh, bp, bn, device=gpu_device, mode="fine_tuning")
+    np.testing.assert_allclose(float(loss), float(gd["ft_loss"]), rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(m.entity_embed.weight.grad.cpu().numpy(), gd["ft_g/entity_embed.weight"], rtol=2e-3,
+                               atol=2e-6)
 
 
 # ----------------------------------------------------------------------------- full-size properties
