@@ -87,7 +87,13 @@ def main():
     ap.add_argument("--edges", type=int, default=None, help="per-GPU edges (default 10M at N=1, 12.5M at N>1)")
     ap.add_argument("--skew", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunks", type=int, default=4, help="tail-row chunks of the backward (comm overlap)")
+    ap.add_argument("--chunks", type=int, default=4, help="rows mode: tail-row chunks of the backward (comm overlap)")
+    ap.add_argument("--sharding", default="features", choices=["features", "rows"],
+                    help="N>1: 'features' = column-sharded tables, no collective in the SpMM, all-to-all exchange; "
+                         "'rows' = head-row ranges + all-reduce of the entity-gradient table")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug only: all ranks share cuda:0 and talk over gloo (N>1 code path on a 1-GPU box); "
+                         "the numbers of such a run are meaningless")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,11 +105,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -112,7 +123,7 @@ def main():
         dist.barrier()
     import literalkg_amd as L
     from literalkg_amd import ops
-    from literalkg_amd.sharding import ShardedAggregation
+    from literalkg_amd.sharding import FeatureShardedAggregation, ShardedAggregation
     from literalkg_amd.synth import make_kg, xavier_table
 
     d = args.dim
@@ -120,8 +131,9 @@ def main():
     e_loc = args.edges or (10_000_000 if world == 1 else 12_500_000)
     n_glob = n_loc * world
     lo, hi = rank * n_loc, (rank + 1) * n_loc
+    mode = "none" if world == 1 else args.sharding
 
-    # this rank's head rows: heads drawn inside [lo, hi), tails over all entities
+    # every rank draws the triples of ITS head rows (heads inside [lo, hi), tails over all entities)
     t0 = time.perf_counter()
     if world == 1:
         h, t, r = make_kg(n_glob, e_loc, args.skew, seed=2022)
@@ -129,30 +141,69 @@ def main():
         hl, _, r = make_kg(n_loc, e_loc, args.skew, seed=2022 + rank)
         h = hl + lo
         t = np.random.default_rng(4044 + rank).integers(0, n_glob, len(h), dtype=np.int64)
+    if mode == "features":      # feature sharding replicates the (small) structure: exchange the triple lists
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.from_numpy(np.stack([h, t, r])).to(cdev).reshape(-1)
+        every = torch.empty(world * mine.numel(), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.view(world, 3, -1)
+        h, t, r = (every[:, i].reshape(-1).cpu().numpy() for i in range(3))
+        del every, mine
     g = L.KGStructure.from_triples(n_glob, h, t, r, device=dev)
     t_build = time.perf_counter() - t0
 
-    ent = xavier_table(n_glob, d, dev, seed=2022)              # same table on every rank (replica)
+    ent = xavier_table(n_glob, d, dev, seed=2022)              # same table on every rank
     relemb = xavier_table(16, d, dev, seed=7)
-    val, _ = ops.edge_softmax(g, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
-    shard = ShardedAggregation(g, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
-    grad_side = torch.randn((hi - lo, d), device=dev)
-    side = torch.empty((hi - lo, d), device=dev)
-    grad_table = torch.empty((n_glob, d), device=dev)
+    ev_n = 3
+    if mode == "features":
+        # real attention values for the whole graph (replicated, like the structure)
+        val, _ = ops.edge_softmax(g, ent, relemb)
+        fs = FeatureShardedAggregation(g, val, rank, world, d, [i * n_loc for i in range(world + 1)])
+        slab = fs.column_slab(ent)
+        del ent
+        dg = fs.dg
+        side_slab = torch.empty((n_glob, dg), device=dev)
+        row_block = torch.empty((world, n_loc, dg), device=dev)
+        grad_block = torch.randn((world, n_loc, dg), device=dev)     # stand-in for the dense part's gradient
+        grad_slab = torch.empty((n_glob, dg), device=dev)
+        grad_table = torch.empty((n_glob, dg), device=dev)
+        fwd_rows, fwd_d, bwd_rows = n_glob, dg, n_glob
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        shard.forward(ent, out=side)
-        if ev is not None:
-            ev[1].record()
-        shard.backward(grad_side, out=grad_table)
-        if ev is not None:
-            ev[2].record()
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            fs.forward(slab, out=side_slab)                    # all edges, my columns: no collective
+            if ev is not None:
+                ev[1].record()
+            fs.to_row_block(side_slab, out=row_block)          # exchange: rows for the dense part ...
+            fs.to_column_slab(grad_block, out=grad_slab)       # ... and its gradient back to column slabs
+            if ev is not None:
+                ev[2].record()
+            fs.backward(grad_slab, out=grad_table)             # A^T, my columns: no collective, no all-reduce
+            if ev is not None:
+                ev[3].record()
+        ev_n = 4
+    else:
+        val, _ = ops.edge_softmax(g, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
+        shard = ShardedAggregation(g, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
+        grad_side = torch.randn((hi - lo, d), device=dev)
+        side = torch.empty((hi - lo, d), device=dev)
+        grad_table = torch.empty((n_glob, d), device=dev)
+        fwd_rows, fwd_d, bwd_rows = hi - lo, d, n_glob
+
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            shard.forward(ent, out=side)
+            if ev is not None:
+                ev[1].record()
+            shard.backward(grad_side, out=grad_table)          # chunked SpMM overlapped with the all-reduce
+            if ev is not None:
+                ev[2].record()
 
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(ev_n)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -163,20 +214,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    nnz_all = torch.tensor([g.nnz], device=dev, dtype=torch.int64)
+    el = torch.tensor([elapsed], dtype=torch.float64)
+    nnz_all = torch.tensor([g.nnz], dtype=torch.int64)
     if world > 1:
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        el, nnz_all = el.to(cdev), nnz_all.to(cdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
+        if mode == "rows":
+            dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
     elapsed = float(el)
     total_entries = int(nnz_all)
 
     # dominant kernel = the forward SpMM launch; HIP events on the launch stream (torch's current stream)
     fwd_ms = np.array([ev[0].elapsed_time(ev[1]) for ev in events])
-    bwd_ms = np.array([ev[1].elapsed_time(ev[2]) for ev in events])
-    by = algorithmic_bytes(g.nnz, hi - lo, d)
+    bwd_ms = np.array([ev[-2].elapsed_time(ev[-1]) for ev in events])
+    xch_ms = np.array([ev[1].elapsed_time(ev[2]) for ev in events]) if ev_n == 4 else None
+    by = algorithmic_bytes(g.nnz, fwd_rows, fwd_d)
     achieved = by / (fwd_ms.mean() * 1e-3) / 1e9
-    by_bwd = algorithmic_bytes(g.nnz, n_glob, d)
+    by_bwd = algorithmic_bytes(g.nnz, bwd_rows, fwd_d)
 
     if rank == 0:
         traffic, traffic_src = pmc_traffic(by) if world == 1 else (None, None)
@@ -187,15 +242,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "REHEARSAL (gloo, one GPU): not a measurement",
             "config": {
                 "workload": f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
-                            + (" + RCCL all-reduce of the entity-gradient table" if world > 1 else "")
+                            + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
+                               "features": " + RCCL all-to-all (column slab <-> row block) both ways"}[mode]
                             + f"; synthetic KG {n_glob} entities / {total_entries} stored (h,t) entries "
                               f"({e_loc * world} triples, R=16, {args.skew} heads)",
                 "entities": n_glob, "stored_entries": total_entries, "triples": e_loc * world, "dim": d,
                 "edge_aggregations_per_step": 2 * total_entries, "passes": ["spmm_csr_fwd", "spmm_csc_bwd"],
-                "sharding": f"head-row ranges x{world}" if world > 1 else "none", "skew": args.skew,
+                "sharding": {"none": "none", "rows": f"head-row ranges x{world}, replicated table, gradient all-reduce",
+                             "features": f"feature columns x{world} (D/G={d // world}), replicated structure, "
+                                         f"all-to-all exchange"}[mode],
+                "skew": args.skew,
                 "host_graph_build_s": round(t_build, 2),
             },
             "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel (forward launch)", "achieved": achieved,
@@ -203,7 +262,8 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
                          "bwd_launch_ms": float(bwd_ms.mean()),
-                         "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if world == 1 else None},
+                         "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if mode != "rows" else None,
+                         "exchange_ms": float(xch_ms.mean()) if xch_ms is not None else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, val, n_glob, d, 2022)

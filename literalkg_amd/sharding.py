@@ -1,6 +1,20 @@
-"""Row-range ("edge-range") sharding of the aggregation hot path across the GPUs of one node
-(SURVEY.md 8e).  One process per GPU; collectives go through torch.distributed (backend "nccl" is
-RCCL over xGMI on ROCm; the same code runs under "gloo" for the CPU rehearsal tests).
+"""Multi-GPU sharding of the aggregation hot path inside one node.  One process per GPU;
+collectives go through torch.distributed (backend "nccl" is RCCL over xGMI on ROCm; the same code runs
+under "gloo" for the CPU rehearsal tests).  Two schemes:
+
+FeatureShardedAggregation (default of bench.py) -- shard the FEATURE dimension.
+  Every column of  side = A @ ego  is independent, so rank g keeps the whole CSR/CSC (a few GB at 100 M
+  edges -- nothing next to 288 GB) and only the D/G columns [g D/G, (g+1) D/G) of every table.  Forward and
+  backward SpMM then need NO collective, the entity-gradient slab is already where its optimizer state
+  lives (no gradient all-reduce at all), and a 128-byte row gather runs at the same HBM efficiency as a
+  1-KiB one (measured).  The exchange step moves to where the layer needs whole rows (Linear / LayerNorm):
+  an all-to-all that turns the N x D/G column slab into a rows_g x D row block and back.  Each rank sends
+  only its own slab, (G-1)/G * N*D*4/G bytes, spread over all 7 xGMI links at once -- 16x less traffic than
+  all-reducing the N x D table on a ring.  The row block arrives as G column panels [G][rows_g][D/G]; the
+  dense part consumes it panel by panel (accumulating MFMA GEMMs, ops.multi_linear) so no transpose copy
+  is ever made.
+
+ShardedAggregation -- shard the HEAD ROWS ("edge-range sharding", the reference-shaped data parallelism).
 
 Partition: head rows are cut into contiguous ranges balanced by stored entries (``lkg_row_partition``),
 so a softmax row never straddles two ranks and ``update_att`` needs no collective.  Every rank keeps
@@ -68,3 +82,70 @@ class ShardedAggregation:
 
 def shard_bounds(graph: KGStructure, world: int) -> List[int]:
     return [int(c) for c in graph.row_cuts(world)]
+
+
+class FeatureShardedAggregation:
+    """Column-sharded aggregation: see the module docstring.
+
+    graph / val: the FULL structure and attention values (replicated on every rank).
+    rank, world, cuts: this rank, the group size and the head-row cut points used for the row layout
+    (``shard_bounds``); d: full feature width (must divide by world)."""
+
+    def __init__(self, graph: KGStructure, val: torch.Tensor, rank: int, world: int, d: int, cuts: List[int],
+                 spmm: Optional[Callable] = None, permute: Optional[Callable] = None, group=None):
+        if spmm is None:
+            from . import ops
+            spmm, permute = ops.spmm_raw, ops.permute_values
+        if d % world:
+            raise ValueError(f"feature width {d} does not divide over {world} ranks")
+        self.spmm, self.graph, self.val = spmm, graph, val
+        self.val_t = permute(val, graph.t_perm)
+        self.rank, self.world, self.d, self.dg = rank, world, d, d // world
+        self.cuts = [int(c) for c in cuts]
+        self.rows = [self.cuts[i + 1] - self.cuts[i] for i in range(world)]
+        self.my_rows = self.rows[rank]
+        self.group = group
+
+    def column_slab(self, table: torch.Tensor) -> torch.Tensor:
+        return table[:, self.rank * self.dg:(self.rank + 1) * self.dg].contiguous()
+
+    def forward(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """side[:, my columns] = A @ ego[:, my columns] over ALL head rows; no communication."""
+        g = self.graph
+        return self.spmm(g.rowptr, g.col, self.val, slab, g.n, out=out, long_rows=g.long_rows(False))
+
+    def backward(self, grad_slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """grad_ego[:, my columns] = A^T @ grad_side[:, my columns]; no communication."""
+        g = self.graph
+        return self.spmm(g.t_rowptr, g.t_col, self.val_t, grad_slab, g.n, out=out, long_rows=g.long_rows(True))
+
+    def to_row_block(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """N x D/G column slab -> this rank's rows as G column panels, shape [G, rows_g, D/G]
+        (panel i = columns of rank i).  One all-to-all."""
+        if out is None:
+            out = torch.empty((self.world, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
+        if self.world == 1:
+            out[0].copy_(slab)
+            return out
+        self._all_to_all(out.view(self.world * self.my_rows, self.dg), slab, [self.my_rows] * self.world, self.rows)
+        return out
+
+    def to_column_slab(self, block: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[G, rows_g, D/G] panels of this rank's rows -> the N x D/G slab of this rank's columns."""
+        if out is None:
+            out = torch.empty((self.graph.n, self.dg), dtype=block.dtype, device=block.device)
+        if self.world == 1:
+            out.copy_(block[0])
+            return out
+        self._all_to_all(out, block.view(self.world * self.my_rows, self.dg), self.rows, [self.my_rows] * self.world)
+        return out
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo moves host memory only (single-GPU rehearsal of the N>1 path): stage through the host
+            host_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                   group=self.group)
+            out.copy_(host_out)
+            return
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)

@@ -62,6 +62,62 @@ def _worker(rank, world, port, n, d, q):
         dist.destroy_process_group()
 
 
+def _feature_worker(rank, world, port, n, d, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from literalkg_amd import KGStructure
+        from literalkg_amd.sharding import FeatureShardedAggregation, shard_bounds
+        rng = np.random.default_rng(21)
+        e = 5000
+        h = (n * rng.random(e) ** 2.0).astype(np.int64)
+        t = rng.integers(0, n, e)
+        g = KGStructure.from_triples(n, h, t, rng.integers(0, 3, e))
+        val = torch.from_numpy(rng.random(g.nnz).astype(np.float32))
+        cuts = shard_bounds(g, world)
+        fs = FeatureShardedAggregation(g, val, rank, world, d, cuts, spmm=cpu_spmm, permute=cpu_permute)
+        x = torch.from_numpy(np.random.default_rng(5).standard_normal((n, d)).astype(np.float32))
+        gside = torch.from_numpy(np.random.default_rng(6).standard_normal((n, d)).astype(np.float32))
+        a = torch.sparse_coo_tensor(g.coo_indices(), val, (n, n)).coalesce()
+        lo, hi = cuts[rank], cuts[rank + 1]
+        cols = slice(rank * fs.dg, (rank + 1) * fs.dg)
+        side_slab = fs.forward(fs.column_slab(x))                      # all rows, my columns
+        ok = torch.allclose(side_slab, torch.matmul(a, x)[:, cols], rtol=1e-5, atol=1e-5)
+        block = fs.to_row_block(side_slab)                             # my rows, all columns, as G panels
+        want_rows = torch.matmul(a, x)[lo:hi]
+        got_rows = torch.cat([block[i] for i in range(world)], dim=1)
+        ok &= torch.allclose(got_rows, want_rows, rtol=1e-5, atol=1e-5)
+        # backward: my rows of grad_side arrive as panels, go back to a column slab, then A^T
+        gblock = torch.stack([gside[lo:hi, i * fs.dg:(i + 1) * fs.dg] for i in range(world)]).contiguous()
+        gslab = fs.to_column_slab(gblock)
+        ok &= torch.equal(gslab, gside[:, cols])
+        gego = fs.backward(gslab)
+        ok &= torch.allclose(gego, torch.matmul(a.t(), gside)[:, cols], rtol=1e-5, atol=1e-4)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 4])
+def test_feature_sharded_forward_exchange_backward(world):
+    import __graft_entry__ as ge
+    ge.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_worker, args=(r, world, port, 403, 24, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)], res
+
+
 @pytest.mark.timeout(120)
 def test_two_rank_sharded_forward_backward():
     import __graft_entry__ as ge
