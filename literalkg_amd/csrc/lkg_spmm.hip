@@ -109,71 +109,63 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
 
 // V: float4 (16-byte chunks) or float.  LPE: lanes per edge.  CPL: chunks per lane.  U: edges in flight.
 // FULL: nchunk == LPE * CPL, i.e. no lane ever falls outside the row (drops the per-load guard).
-// Rows longer than long_thresh (> 0) are left to spmm_long_rows_kernel.
+//
+// One launch, two kinds of workgroup (256 threads = 4 waves each):
+//   blocks [0, n_long)   : one LONG row (> long_thresh entries, listed in long_rows) per workgroup -- the four
+//                          waves take interleaved 64-entry chunks, partial sums meet in LDS and are added in a
+//                          fixed order (deterministic, no atomics).  They are dispatched first, so the longest
+//                          rows of a skewed graph overlap the bulk instead of being the tail of the launch.
+//   blocks [n_long, ...) : four ordinary rows, one wave each (rows over the threshold are skipped here).
 template <typename V, int LPE, int CPL, int U, bool FULL>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                                                         const int *__restrict__ rowptr,
                                                         const int *__restrict__ col,
                                                         const float *__restrict__ val,
                                                         const float *__restrict__ x, long ldx,
-                                                        float *__restrict__ out, long ldo, int long_thresh) {
+                                                        float *__restrict__ out, long ldo,
+                                                        const int *__restrict__ long_rows, int n_long,
+                                                        int long_thresh) {
     using ops = vec_ops<V>;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
-    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
-    if (long_thresh > 0 && end - start > long_thresh) return;
-    V acc[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
-    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, 0, 1, lane, nchunk, col, val, x, ldx);
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
-    if (lane / LPE == 0) {
-        V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int chunk = lane % LPE + i * LPE;
-            if (FULL || chunk < nchunk) dst[chunk] = acc[i];
-        }
-    }
-}
-
-// Rows longer than the threshold: one workgroup of LONG_WAVES waves per row, the waves take interleaved
-// 64-entry chunks, partial sums meet in LDS and are added in a fixed order (deterministic, no atomics).
-constexpr int LONG_WAVES = 8;
-template <typename V, int LPE, int CPL, int U, bool FULL>
-__global__ __launch_bounds__(64 * LONG_WAVES) void spmm_long_rows_kernel(int nchunk, const int *__restrict__ long_rows,
-                                                                          const int *__restrict__ rowptr,
-                                                                          const int *__restrict__ col,
-                                                                          const float *__restrict__ val,
-                                                                          const float *__restrict__ x, long ldx,
-                                                                          float *__restrict__ out, long ldo) {
-    using ops = vec_ops<V>;
-    __shared__ V part[LONG_WAVES][CPL][LPE];
+    __shared__ V part[4][CPL][LPE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = long_rows[blockIdx.x];
+    const bool team = (int)blockIdx.x < n_long;     // workgroup-uniform
+    int row;
+    if (team) {
+        row = long_rows[blockIdx.x];
+    } else {
+        row = ((int)blockIdx.x - n_long) * 4 + w;
+        if (row >= n_rows) return;
+    }
     const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
     const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    if (!team && n_long > 0 && end - start > long_thresh) return;
     V acc[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
-    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, w, LONG_WAVES, lane, nchunk, col, val, x, ldx);
+    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val, x,
+                                             ldx);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
-    if (lane < LPE)
+    if (team) {
+        if (lane < LPE)
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) part[w][i][lane] = acc[i];
-    __syncthreads();
-    if (w == 0 && lane < LPE) {
+            for (int i = 0; i < CPL; ++i) part[w][i][lane] = acc[i];
+        __syncthreads();
+        if (w != 0) return;
+        if (lane < LPE)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                acc[i] = part[0][i][lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) ops::fma(acc[i], 1.f, part[k][i][lane]);
+            }
+    }
+    if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            V s = part[0][i][lane];
-            for (int k = 1; k < LONG_WAVES; ++k) ops::fma(s, 1.f, part[k][i][lane]);
             const int chunk = lane + i * LPE;
-            if (FULL || chunk < nchunk) dst[chunk] = s;
+            if (FULL || chunk < nchunk) dst[chunk] = acc[i];
         }
     }
 }
@@ -181,14 +173,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void spmm_long_rows_kernel(int nch
 template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
            int64_t ldx, float *out, int64_t ldo, const int *long_rows, int n_long, int long_thresh, hipStream_t s) {
-    const int rows_per_block = 4;
-    const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
-    if (n_long > 0)   // longest first: they would otherwise be the tail of the launch
-        hipLaunchKernelGGL((spmm_long_rows_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)n_long),
-                           dim3(64 * LONG_WAVES), 0, s, nchunk, long_rows, rowptr, col, val, x, (long)ldx, out,
-                           (long)ldo);
+    const int64_t blocks = (n_rows + 3) / 4 + n_long;
     hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows,
-                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, n_long > 0 ? long_thresh : 0);
+                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, long_rows, n_long, long_thresh);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
