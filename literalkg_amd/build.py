@@ -26,7 +26,8 @@ def build(force=False, verbose=True):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build literalkg_amd/lib/liblkg_hip.so")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-o", LIB] + \
+    extra = os.environ.get("LKG_EXTRA_HIPCC_FLAGS", "").split()      # kernel A/B experiments only
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-o", LIB] + extra + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

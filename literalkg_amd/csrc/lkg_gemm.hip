@@ -4,11 +4,21 @@
 //   C[m,n] = alpha * sum_k opA(A)[m,k] * opB(B)[k,n] + beta * C[m,n] (+ bias[n])
 //
 // Tiling: 128 x 128 x 16 block tile, 256 threads = 4 waves in 2 x 2, each wave a 64 x 64 tile as 2 x 2
-// MFMA 32x32 accumulators (64 accumulator registers).  Both operands are staged K-MAJOR in LDS
-// (As[k][m], Bs[k][n], row pitch 132 floats) so that the MFMA operand read -- lane l needs
-// A[m = l & 31][k = l >> 5] -- is one conflict-free ds_read_b32 per operand: 32 consecutive floats per
-// half-wave, the two halves one k-row apart.  Global loads of tile t+1 are issued before the MFMAs of
-// tile t and written to the other LDS buffer afterwards (one barrier per k-tile).
+// MFMA 32x32 accumulators (64 accumulator registers).
+//
+// LDS images follow the GLOBAL layout of each operand, so staging is always a straight 16-byte copy
+// (no transposing scatter):
+//   K-contiguous operand (A row-major, or B given transposed = nn.Linear weight): image [row][k], pitch 20
+//     floats; a lane fetches FOUR consecutive k of its row with one ds_read_b128 (conflict-free: 20 l mod 64
+//     hits 16 distinct 4-bank slots for any 16 lanes of a half-wave);
+//   M/N-contiguous operand (A given transposed, B row-major): image [k][col], pitch 132 floats; a lane
+//     fetches its four k with four ds_read_b32 (32 consecutive floats per half-wave, halves one row apart).
+// The 32x32x2 MFMA wants k = 0 on lanes 0-31 and k = 1 on lanes 32-63.  Inside a group of 8 k the four
+// MFMAs take k = j on the lower half and k = 4 + j on the upper half (j = 0..3): any pairing is legal as
+// long as A and B agree, and this one lets a lane read 4 consecutive k.
+// Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer
+// afterwards (one barrier per k-tile).  Workgroup ids are remapped so that each XCD walks a contiguous
+// range of tiles (n fastest): the tiles that share an A panel run on the same L2 (measured +1 %).
 //
 // Grouped forms (relation-grouped W_r GEMM, model.py:372/390-395 without materialising W_r[r]):
 //   rows mode : rows [seg[g], seg[g+1]) of A and C use B + g * stride_b     (projection, data gradient)
@@ -23,7 +33,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, PITCH = 132;
+constexpr int BM = 128, BN = 128, BK = 16;   // BK = 32 measured slower on the tall-skinny shapes (occupancy)
+constexpr int EPT = BK / 2;      // floats per thread per operand tile (128 * BK / 256)
+constexpr int PK = BK + 4;      // pitch of a [row][k] image
+constexpr int PM = BM + 4;      // pitch of a [k][col] image
+constexpr int IMG = (BM * PK > BK * PM) ? BM * PK : BK * PM;   // floats per operand image
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
@@ -43,66 +57,100 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-// Stage a (rows x BK) tile whose global layout has K contiguous (A not transposed / B transposed):
-// element (r, k) at src[r * ld + k].  Thread t owns row t/2 and 8 consecutive k.
-struct KContigLoader {
-    float v[8];
+// K-contiguous operand: element (r, k) at src[r * ld + k]; LDS image [r][k].  Thread t owns row t/2 and
+// EPT = 8 consecutive k.
+struct KContig {
+    float v[EPT];
     __device__ __forceinline__ void load(const float *src, long ld, long r0, long r_end, long k0, long k_end, int t,
                                          bool fast) {
         const long r = r0 + (t >> 1);
-        const long k = k0 + (t & 1) * 8;
+        const long k = k0 + (t & 1) * EPT;
         if (fast) {
             const float4 *p = reinterpret_cast<const float4 *>(src + r * ld + k);
-            const float4 x = p[0], y = p[1];
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (r < r_end && k + j < k_end) ? src[r * ld + k + j] : 0.f;
+            for (int q = 0; q < EPT / 4; ++q) {
+                const float4 x = p[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+        } else {
+            // edge tile / unaligned operand: branch-free (clamped address + select) so that the loads stay
+            // in flight across the MFMAs instead of being fenced by a wait at every guard's join
+            const float *row = src + min(r, r_end - 1) * ld;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float x = row[min(k + j, k_end - 1)];
+                v[j] = (r < r_end && k + j < k_end) ? x : 0.f;
+            }
         }
     }
     __device__ __forceinline__ void store(float *lds, int t) const {
-        const int r = t >> 1, k = (t & 1) * 8;
+        float *p = lds + (t >> 1) * PK + (t & 1) * EPT;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lds[(k + j) * PITCH + r] = v[j];
+        for (int q = 0; q < EPT / 4; ++q)
+            *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    // the 4 k-values of MFMA group g for the 32 rows starting at r0 (lane l: row r0 + (l & 31))
+    static __device__ __forceinline__ float4 frag(const float *lds, int r0, int g, int lane) {
+        return *reinterpret_cast<const float4 *>(lds + (r0 + (lane & 31)) * PK + 8 * g + (lane >> 5) * 4);
     }
 };
 
-// Stage a (BK x cols) tile whose global layout has the m/n index contiguous (A transposed / B not
-// transposed): element (k, c) at src[k * ld + c].  Thread t owns k = t/16 and 8 consecutive columns.
-struct MContigLoader {
-    float v[8];
+// M/N-contiguous operand: element (k, c) at src[k * ld + c]; LDS image [k][c].  Thread t owns k = t/16 and
+// EPT = 8 consecutive columns.
+struct MContig {
+    static constexpr int TPK = BM / EPT;   // threads per k-row
+    float v[EPT];
     __device__ __forceinline__ void load(const float *src, long ld, long c0, long c_end, long k0, long k_end, int t,
                                          bool fast) {
-        const long k = k0 + (t >> 4);
-        const long c = c0 + (t & 15) * 8;
+        const long k = k0 + t / TPK;
+        const long c = c0 + (t % TPK) * EPT;
         if (fast) {
             const float4 *p = reinterpret_cast<const float4 *>(src + k * ld + c);
-            const float4 x = p[0], y = p[1];
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (k < k_end && c + j < c_end) ? src[k * ld + c + j] : 0.f;
+            for (int q = 0; q < EPT / 4; ++q) {
+                const float4 x = p[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+        } else {
+            const float *row = src + min(k, k_end - 1) * ld;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float x = row[min(c + j, c_end - 1)];
+                v[j] = (k < k_end && c + j < c_end) ? x : 0.f;
+            }
         }
     }
     __device__ __forceinline__ void store(float *lds, int t) const {
-        float *p = lds + (t >> 4) * PITCH + (t & 15) * 8;
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        float *p = lds + (t / TPK) * PM + (t % TPK) * EPT;
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q)
+            *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    static __device__ __forceinline__ float4 frag(const float *lds, int c0, int g, int lane) {
+        const float *p = lds + (8 * g + (lane >> 5) * 4) * PM + c0 + (lane & 31);
+        return make_float4(p[0], p[PM], p[2 * PM], p[3 * PM]);
     }
 };
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * PITCH];
+    __shared__ __attribute__((aligned(16))) float As[2][IMG];
+    __shared__ __attribute__((aligned(16))) float Bs[2][IMG];
+    using LA = typename std::conditional<TA, MContig, KContig>::type;
+    using LB = typename std::conditional<TB, KContig, MContig>::type;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tile = blockIdx.x;
+    // XCD-aware remap: workgroup b runs on XCD b % 8; give every XCD a contiguous range of logical tiles
+    const int tiles = g.tiles_m * g.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int cpx = tiles >> 3, rem = tiles & 7;
+        const int x = tile & 7, slot = tile >> 3;
+        tile = x * cpx + min(x, rem) + slot;
+    }
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int z = blockIdx.y;
 
@@ -127,9 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const long m0 = m_lo + (long)tm * BM;
     const long n0 = (long)tn * BN;
     if (m0 >= m_hi || n0 >= g.n) return;
-    if (k_lo >= k_hi && (g.mode != 2)) {
-        if (atomic_out) return;
-    }
+    if (atomic_out && k_lo >= k_hi) return;
 
     // can this block use unguarded 16-byte loads?
     const bool a_al = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -144,12 +190,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    typename std::conditional<TA, MContigLoader, KContigLoader>::type la;
-    typename std::conditional<TB, KContigLoader, MContigLoader>::type lb;
-
+    LA la;
+    LB lb;
     auto fetch = [&](long k0) {
         const bool k_full = k0 + BK <= k_hi;
-        // k offsets are multiples of 8 from k_lo; 16-byte alignment along k needs k_lo % 4 == 0
         if constexpr (TA)
             la.load(A, g.lda, m0, m_hi, k0, k_hi, t, a_al && m_full && k_full && (m0 % 4 == 0));
         else
@@ -170,16 +214,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (long k0 = k_lo; k0 < k_hi; k0 += BK) {
         const bool more = k0 + BK < k_hi;
         if (more) fetch(k0 + BK);
-        const float *as = As[buf] + wm * 64 + (lane & 31) + (lane >> 5) * PITCH;
-        const float *bs = Bs[buf] + wn * 64 + (lane & 31) + (lane >> 5) * PITCH;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = as[kk * PITCH], a1 = as[kk * PITCH + 32];
-            const float b0 = bs[kk * PITCH], b1 = bs[kk * PITCH + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int grp = 0; grp < BK / 8; ++grp) {
+            const float4 a0 = LA::frag(As[buf], wm * 64, grp, lane), a1 = LA::frag(As[buf], wm * 64 + 32, grp, lane);
+            const float4 b0 = LB::frag(Bs[buf], wn * 64, grp, lane), b1 = LB::frag(Bs[buf], wn * 64 + 32, grp, lane);
+#define LKG_STEP(F)                                                                         \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.F, b0.F, acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.F, b1.F, acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.F, b0.F, acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.F, b1.F, acc[1][1], 0, 0, 0);
+            LKG_STEP(x) LKG_STEP(y) LKG_STEP(z) LKG_STEP(w)
+#undef LKG_STEP
         }
         if (more) {
             la.store(As[buf ^ 1], t);
