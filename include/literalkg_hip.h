@@ -79,10 +79,14 @@ int lkg_row_partition(int64_t n_rows, const int32_t *rowptr, int32_t n_parts, in
  * long_rows (nullable, device int32[n_long]): the rows (relative to rowptr) holding more than
  * long_thresh entries; each of them gets a whole workgroup instead of one wave so that a skewed
  * degree distribution does not leave one wave as the tail of the launch.  The list must contain
- * exactly the rows with > long_thresh entries (KGStructure builds it on the host).             */
+ * exactly the rows with > long_thresh entries (KGStructure builds it on the host).
+ * self (nullable, n_rows x d, stride ld_self): out[i,:] = self[i,:] + sum ... , i.e. the
+ * `ego + side` of the gcn / bi-interaction / gin layers (model.py:109, 123, 132) without a second
+ * pass; in the backward the same flag adds the incoming gradient (d(ego+side)/d ego = I + A^T).   */
 int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                      const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
-                     const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
+                     const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
+                     int32_t long_thresh, void *stream);
 
 /* K1+K2  attention refresh, fused: per stored entry
  *     v = sum over its raw edges e of  sum_d ent[t,d] * tanh(ent[h,d] + relemb[rel[e],d])

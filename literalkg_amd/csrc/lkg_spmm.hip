@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                                                         const float *__restrict__ val,
                                                         const float *__restrict__ x, long ldx,
                                                         float *__restrict__ out, long ldo,
+                                                        const float *__restrict__ self, long ld_self,
                                                         const int *__restrict__ long_rows, int n_long,
                                                         int long_thresh) {
     using ops = vec_ops<V>;
@@ -162,33 +163,40 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     }
     if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
+        const V *own = self ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int chunk = lane + i * LPE;
-            if (FULL || chunk < nchunk) dst[chunk] = acc[i];
+            if (FULL || chunk < nchunk) {
+                if (own) ops::fma(acc[i], 1.f, own[chunk]);   // out = self + A @ x  (ego + side, model.py:109)
+                dst[chunk] = acc[i];
+            }
         }
     }
 }
 
 template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
-           int64_t ldx, float *out, int64_t ldo, const int *long_rows, int n_long, int long_thresh, hipStream_t s) {
+           int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
+           int long_thresh, hipStream_t s) {
     const int64_t blocks = (n_rows + 3) / 4 + n_long;
     hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows,
-                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, long_rows, n_long, long_thresh);
+                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self, long_rows, n_long,
+                       long_thresh);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
 
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
-             int64_t ldx, float *out, int64_t ldo, const int *long_rows, int n_long, int long_thresh, hipStream_t s) {
+             int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
+             int long_thresh, hipStream_t s) {
 #define LKG_GO(LPE, CPL, U)                                                                              \
     return (nchunk == LPE * CPL)                                                                         \
-               ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, long_rows,  \
-                                              n_long, long_thresh, s)                                    \
-               : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, long_rows, \
-                                               n_long, long_thresh, s)
+               ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
+                                              long_rows, n_long, long_thresh, s)                          \
+               : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
+                                               long_rows, n_long, long_thresh, s)
     if (nchunk <= 8) LKG_GO(8, 1, 4);
     if (nchunk <= 16) LKG_GO(16, 1, 4);
     if (nchunk <= 32) LKG_GO(32, 1, 4);
@@ -203,7 +211,8 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
 
 extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                                 const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
-                                const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
+                                const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
+                                int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -213,15 +222,17 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     if (n_rows == 0) return LKG_OK;
     LKG_REQUIRE(rowptr && x && out, "lkg_spmm_csr_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out);
+    LKG_REQUIRE(!self || ld_self >= d, "lkg_spmm_csr_f32: self stride %lld smaller than d=%d", (long long)ld_self, d);
+    const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out) &&
+                     (!self || (ld_self % 4 == 0 && lkg_aligned16(self)));
     const int width = vec ? 4 : 1;
     const int block_cols = 256 * width;   // columns one launch covers (CPL <= 4)
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
-        int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, long_rows, n_long,
-                                        long_thresh, s)
-                     : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo, long_rows, n_long,
-                                       long_thresh, s);
+        int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
+                                        self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, s)
+                     : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
+                                       self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, s);
         if (rc != LKG_OK) return rc;
     }
     return LKG_OK;

@@ -35,8 +35,9 @@ class AttentionCSR:
         self.val_t = val_t if val_t is not None else (
             ops.permute_values(val, graph.t_perm) if graph.t_perm is not None and val.is_cuda else None)
 
-    def aggregate(self, ego: torch.Tensor) -> torch.Tensor:
-        return ops.aggregate(ego, self.graph, self.val, self.val_t)
+    def aggregate(self, ego: torch.Tensor, plus_self: bool = False) -> torch.Tensor:
+        """A_in @ ego  (plus_self: ego + A_in @ ego in the same pass)."""
+        return ops.aggregate(ego, self.graph, self.val, self.val_t, plus_self)
 
 
 def _xavier(linear: nn.Linear) -> nn.Linear:
@@ -118,12 +119,14 @@ class Aggregator(nn.Module):
 
     def forward(self, ego_embeddings, A_in: AttentionCSR, all_layers, lamda, alpha, l):
         ego = ego_embeddings
-        side = A_in.aggregate(ego)
         h0 = all_layers[0]
         kind = self.aggregator_type
-        if kind == "gcn":
-            z = self._lin(self.linear, self.residual_connection(ego + side, h0, lamda, alpha, l))
+        if kind == "gcn":   # ego + side comes out of the SpMM directly
+            z = self._lin(self.linear, self.residual_connection(A_in.aggregate(ego, True), h0, lamda, alpha, l))
             return self._finish(z)
+        if kind == "gin":
+            return self._gin(ego, A_in.aggregate(ego, True), h0, all_layers, lamda, alpha, l)
+        side = A_in.aggregate(ego)
         if kind == "graphsage":
             if self.use_residual:
                 wh = self.linear_h.weight
@@ -140,12 +143,15 @@ class Aggregator(nn.Module):
             # slope-1 epilogue for the LayerNorm
             z = F.leaky_relu(b, ops.LEAKY_SLOPE) + F.leaky_relu(s, ops.LEAKY_SLOPE)
             return self._finish(z, slope=1.0)
-        # gin (model.py:131-158)
+        raise NotImplementedError(kind)
+
+    def _gin(self, ego, ego_plus_side, h0, all_layers, lamda, alpha, l):
+        """model.py:131-158"""
         if self.num_layers == 1:
             raise AttributeError("gin with n_mlp_layers == 1 cannot run in the reference either "
                                  "(inp_linear/out_linear are never created, model.py:66-68, 133)")
         stack = self._lin(self.inp_linear, ego)
-        h = self._lin(self.inp_linear, ego + side)
+        h = self._lin(self.inp_linear, ego_plus_side)
         for lin, norm in zip(self.linears, self.mlp_layer_norms):
             h, _ = ops.act_layernorm(self._lin(lin, h), norm.weight, norm.bias, want_norm=False)
             stack = stack + h

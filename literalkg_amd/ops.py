@@ -53,17 +53,21 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
-             x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[i,:] = sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows described by rowptr
-    (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets a
-    row-range shard hand over only ITS rows of x while col keeps global ids."""
+             x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
+             add_self: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i,:] = (add_self[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows described
+    by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
+    a row-range shard hand over only ITS rows of x while col keeps global ids."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
     if out is None:
         out = torch.empty((n_rows, d), dtype=torch.float32, device=x.device)
+    if add_self is not None:
+        add_self = _f32_rows(add_self)
     N.call("lkg_spmm_csr_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
-           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(long_rows),
+           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
+           _ld(add_self) if add_self is not None else 0, N.ptr(long_rows),
            0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
     return out
 
@@ -127,22 +131,28 @@ class _Aggregate(Function):
     model.py:261)."""
 
     @staticmethod
-    def forward(ctx, ego, g: KGStructure, val, val_t):
+    def forward(ctx, ego, g: KGStructure, val, val_t, plus_self):
         _need_gpu(ego, val)
         ctx.g = g
         ctx.val_t = val_t
-        return spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False))
+        ctx.plus_self = plus_self
+        return spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
+                        add_self=ego if plus_self else None)
 
     @staticmethod
     def backward(ctx, grad):
         g = ctx.g
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
-        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True)), None, None, None
+        grad = _f32_rows(grad)
+        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True),
+                        add_self=grad if ctx.plus_self else None), None, None, None, None
 
 
-def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor) -> torch.Tensor:
-    return _Aggregate.apply(ego, g, val, val_t)
+def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor,
+              plus_self: bool = False) -> torch.Tensor:
+    """side = A @ ego, or ego + side in one pass when plus_self."""
+    return _Aggregate.apply(ego, g, val, val_t, plus_self)
 
 
 # ----------------------------------------------------------------------------- dense layers on the MFMA GEMM

@@ -43,7 +43,7 @@ def test_error_convention(native):
     with pytest.raises(native.LkgError, match="null"):
         native.call("lkg_csr_build", 3, 2, None, native.ptr(t), None, *[native.ptr(o) for o in out])
     with pytest.raises(native.LkgError, match="d must be positive"):
-        native.call("lkg_spmm_csr_f32", 4, 0, None, None, None, None, 0, None, 0, None, 0, 0, None)
+        native.call("lkg_spmm_csr_f32", 4, 0, None, None, None, None, 0, None, 0, None, 0, None, 0, 0, None)
 
 
 def numpy_csr(n, h, t, r):

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def cpu_spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None):
+def cpu_spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, add_self=None):
     rp = rowptr.long()
     lo, hi = int(rp[0]), int(rp[-1])
     rows = torch.repeat_interleave(torch.arange(n_rows), rp[1:] - rp[:-1])
