@@ -81,7 +81,7 @@ def laplacian(n, h, t, r):
 
 
 def sd_to_np(sd):
-    return {"p/" + k: v.detach().cpu().numpy() for k, v in sd.items() if k != "A_in"}
+    return {"p/" + k: v.detach().cpu().numpy().copy() for k, v in sd.items() if k != "A_in"}
 
 
 def build(cls, args, n, n_rel, a_in, num, txt, seed):
@@ -180,9 +180,59 @@ def encoder_case(cls, name, args, n, h, t, r, seed, form, rng):
     return m
 
 
+def trajectory_case(ref_model, name, args, n, h, t, r, seed, n_steps, refresh_after, rng):
+    """A short training run of the REFERENCE shaped like pre_training_train (main_pretraining.py:86-139):
+    Adam steps on fresh batches, one update_att in the middle, losses recorded per step."""
+    n_rel = int(r.max()) + 1
+    a_in = laplacian(n, h, t, r)
+    num = torch.from_numpy(rng.random((n, args["num_lit_dim"])).astype(np.float32)) if args["use_num_lit"] else None
+    txt = torch.from_numpy(rng.standard_normal((n, args["txt_lit_dim"])).astype(np.float32)) if args["use_txt_lit"] else None
+    m = build(ref_model.LiteralKG, args, n, n_rel, a_in, num, txt, seed)
+    m.train()                                  # mess_dropout = 0 in args: train mode is deterministic
+    init = sd_to_np(m.state_dict())
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    dev = torch.device("cpu")
+    k, groups = args["pre_training_neg_rate"], 30
+    batches, losses = [], []
+    ht, tt, rt = (torch.from_numpy(x) for x in (h, t, r))
+    for step in range(n_steps):
+        b = [np.repeat(rng.integers(0, n, groups), k), np.repeat(rng.integers(0, n_rel, groups), k),
+             np.repeat(rng.integers(0, n, groups), k), rng.integers(0, n, groups * k)]
+        batches.append(np.stack(b))
+        opt.zero_grad()
+        loss = m(*[torch.from_numpy(x) for x in b], device=dev, mode="pre_training")
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if step == refresh_after:
+            m(ht, tt, rt, list(range(n_rel)), device=dev, mode="update_att")
+    final = {"f/" + k_: v.detach().numpy() for k_, v in m.state_dict().items() if k_ != "A_in"}
+    a = m.A_in.data.coalesce()
+    arrs = dict(cfg=np.array(json.dumps(args)), n=np.int64(n), n_rel=np.int64(n_rel), h=h, t=t, r=r,
+                a_indices=a_in.indices().numpy(), a_values=a_in.values().numpy(), batches=np.stack(batches),
+                losses=np.array(losses, np.float64), refresh_after=np.int64(refresh_after), lr=np.float64(1e-2),
+                final_a_indices=a.indices().numpy(), final_a_values=a.values().numpy())
+    if num is not None:
+        arrs["num"] = num.numpy()
+    if txt is not None:
+        arrs["txt"] = txt.numpy()
+    arrs.update(init)
+    arrs.update(final)
+    save(name, **arrs)
+
+
 def main():
     ref_model, ref_model_bce = ref_modules()
     rng = np.random.default_rng(2022)
+    if "--only-trajectory" in sys.argv:
+        rng = np.random.default_rng(777)
+        th, tt_, tr = random_graph(rng, 200, 1400, 4, 6)
+        trajectory_case(ref_model, "trajectory_gcn_l2_gatemul_scale",
+                        make_args(n_conv_layers=2, scale_gat_dim=16, use_num_lit=True, use_txt_lit=True),
+                        200, th, tt_, tr, 99, 6, 2, rng)
+        trajectory_case(ref_model, "trajectory_bi_l1",
+                        make_args(aggregation_type="bi-interaction"), 200, th, tt_, tr, 98, 5, 1, rng)
+        return
 
     # ---- attention ------------------------------------------------------
     # 5-node toy with a duplicate (h,t) pair under two relations (SURVEY 3.2)

@@ -412,6 +412,33 @@ def test_fine_tuning_head_matches_reference_fixture(L, gpu_device, name):
                                atol=2e-6)
 
 
+@pytest.mark.parametrize("name", golden_names("trajectory_"))
+def test_training_trajectory_matches_reference(L, gpu_device, name):
+    """The drop-in module driven like pre_training_train (main_pretraining.py:86-139): Adam steps on the device,
+    update_att in the middle, against the losses / final weights / final A_in the REFERENCE produced."""
+    gd = load_golden(name)
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.train()                                            # mess_dropout = 0 in this fixture
+    opt = torch.optim.Adam(m.parameters(), lr=float(gd["lr"]))
+    h, t, r = (torch.from_numpy(gd[k]).to(gpu_device) for k in "htr")
+    for step, b in enumerate(gd["batches"]):
+        opt.zero_grad()
+        loss = m(*[torch.from_numpy(x).to(gpu_device) for x in b], device=gpu_device, mode="pre_training")
+        assert not np.isnan(loss.cpu().detach().numpy())          # the caller's NaN check, main_pretraining.py:112
+        loss.backward()
+        opt.step()
+        np.testing.assert_allclose(loss.item(), gd["losses"][step], rtol=1e-4, err_msg=f"step {step}")
+        if step == int(gd["refresh_after"]):
+            m(h, t, r, list(range(int(gd["n_rel"]))), device=gpu_device, mode="update_att")
+    a = m.A_in.data.cpu().coalesce()
+    assert np.array_equal(a.indices().numpy(), gd["final_a_indices"])
+    np.testing.assert_allclose(a.values().numpy(), gd["final_a_values"], rtol=1e-3, atol=1e-6)
+    sd = m.state_dict()
+    for k, want in gd.items():
+        if k.startswith("f/") and k[2:] in sd:
+            np.testing.assert_allclose(sd[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-5, err_msg=k)
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(L, ops, gpu_device):
     """BASELINE config shape (1M entities / 10M edges / D=256): size-independent properties."""

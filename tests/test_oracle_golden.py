@@ -94,3 +94,30 @@ def test_laplacian_matches_fixture_inputs():
     a = O.laplacian_a_in(int(g["n"]), h, t, r)
     assert np.array_equal(a.indices().numpy(), g["a_indices"])
     np.testing.assert_allclose(a.values().numpy(), g["a_values"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("trajectory_"))
+def test_training_trajectory(name):
+    """Oracle + torch Adam replays the reference's short training run (Adam steps, update_att in the middle)."""
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    n = int(g["n"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in golden_params(g).items()}
+    a = torch.sparse_coo_tensor(torch.from_numpy(g["a_indices"]), torch.from_numpy(g["a_values"]), (n, n)).coalesce()
+    num = torch.from_numpy(g["num"]) if "num" in g else None
+    txt = torch.from_numpy(g["txt"]) if "txt" in g else None
+    opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=float(g["lr"]))
+    h, t, r = (torch.from_numpy(g[k]) for k in "htr")
+    for step, b in enumerate(g["batches"]):
+        opt.zero_grad()
+        loss = O.pre_training_loss(p, cfg, a, *[torch.from_numpy(x) for x in b], num=num, txt=txt)
+        loss.backward()
+        opt.step()
+        np.testing.assert_allclose(float(loss), g["losses"][step], rtol=1e-5, err_msg=f"step {step}")
+        if step == int(g["refresh_after"]):
+            with torch.no_grad():
+                a = O.attention_refresh(n, p["entity_embed.weight"], p["relation_embed.weight"], h, t, r).coalesce()
+    assert np.array_equal(a.indices().numpy(), g["final_a_indices"])
+    np.testing.assert_allclose(a.values().numpy(), g["final_a_values"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p["entity_embed.weight"].detach().numpy(), g["f/entity_embed.weight"], rtol=1e-4,
+                               atol=1e-6)
