@@ -71,6 +71,24 @@ int lkg_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t
  * SURVEY.md 8e).  cuts int64[n_parts+1].                                     */
 int lkg_row_partition(int64_t n_rows, const int32_t *rowptr, int32_t n_parts, int64_t *cuts);
 
+/* f3  graph ingestion.  Text file of "h r t" lines (single spaces), as
+ * DataLoader.load_graph reads with pandas (dataloader.py:186-190).  Two calls: count, then read into
+ * caller-sized int64 arrays.  A malformed line is an error (LKG_ERR_INVALID_ARG).              */
+int lkg_triples_count(const char *path, int64_t *n_lines);
+int lkg_triples_read(const char *path, int64_t capacity, int64_t *h, int64_t *r, int64_t *t,
+                     int64_t *n_read);
+/* drop_duplicates(keep='first') (dataloader.py:189): keep int64[<=n] lists, in input order, the first
+ * occurrence of every distinct (h, r, t).                                                       */
+int lkg_triples_dedup(int64_t n, const int64_t *h, const int64_t *r, const int64_t *t, int64_t *keep,
+                      int64_t *n_keep);
+/* Initial attention values of the loader, A_in = sum_r norm(A_r) (dataloader.py:449-495), written in
+ * the entry order of the structure built by lkg_csr_build.  kind 0 = 'random-walk' (D_r^-1 A_r),
+ * kind 1 = 'symmetric' (D_r^-1/2 A_r D_r^-1/2 with the ROW sums on both sides, as the reference).
+ * All pointers are HOST memory.                                                                 */
+int lkg_laplacian_f32(int64_t n_entities, int64_t n_raw, int64_t nnz, const int32_t *rowptr,
+                      const int32_t *col, const int32_t *eptr, const int32_t *rel, int32_t kind,
+                      float *val_out);
+
 /* ---------------------------------------------------------------- device --
  * K3/K4  neighbour aggregation  out[i,:] = sum_{j in row i} val[j] * x[col[j],:]
  * Replaces torch.matmul(A_in, ego) (model.py:106); called with the CSC arrays

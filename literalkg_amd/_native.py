@@ -14,6 +14,10 @@ PROTOTYPES = {
     "lkg_csr_build": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_csr_transpose": [i64, i64, i64, vp, vp, vp, vp, vp],
     "lkg_row_partition": [i64, vp, i32, vp],
+    "lkg_triples_count": [C.c_char_p, vp],
+    "lkg_triples_read": [C.c_char_p, i64, vp, vp, vp, vp],
+    "lkg_triples_dedup": [i64, vp, vp, vp, vp, vp],
+    "lkg_laplacian_f32": [i64, i64, i64, vp, vp, vp, vp, i32, vp],
     "lkg_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp],
     "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp],
     "lkg_permute_f32": [i64, vp, vp, vp, vp],

@@ -1,12 +1,20 @@
 // Host-side KG structure build: (head, tail)-sorted CSR with merged duplicate pairs,
-// its CSC transpose, and nnz-balanced row-range cuts.  Plain C++ (no device code).
+// its CSC transpose, nnz-balanced row-range cuts, and the text ingestion of "h r t" files
+// with the loader's initial attention values.  Plain C++ (no device code).
 //
 // What it replaces in the reference: the per-relation torch.where / cat / stack /
 // sparse COO assembly + coalesce() of LiteralKG.update_attention (model.py:451-470)
 // and the scipy COO -> tensor assembly of DataLoader (dataloader.py:449-495).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -148,5 +156,197 @@ extern "C" int lkg_row_partition(int64_t n_rows, const int32_t *rowptr, int32_t 
         cuts[p] = std::max(cuts[p - 1], std::min<int64_t>(row, n_rows));
     }
     cuts[n_parts] = n_rows;
+    return LKG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f3  graph ingestion: the reference parses "h r t" text with pandas (engine='python'),
+// drops duplicate rows and walks the frame with iterrows() (dataloader.py:186-190, 369-424), then builds
+// per-relation scipy matrices for the initial A_in (dataloader.py:449-495).  Here: one pass over the file
+// with a hand-rolled integer parser, an index sort for the duplicate drop, and the Laplacian values
+// computed directly on the (head, tail)-sorted structure.
+namespace {
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~Mapped() {
+        if (p && n) munmap(const_cast<char *>(p), n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+int map_file(const char *path, Mapped &m) {
+    m.fd = open(path, O_RDONLY);
+    if (m.fd < 0) {
+        lkg_set_error("cannot open %s: %s", path, strerror(errno));
+        return LKG_ERR_INVALID_ARG;
+    }
+    struct stat st;
+    if (fstat(m.fd, &st) != 0) {
+        lkg_set_error("cannot stat %s: %s", path, strerror(errno));
+        return LKG_ERR_INVALID_ARG;
+    }
+    m.n = (size_t)st.st_size;
+    if (m.n == 0) return LKG_OK;
+    void *a = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
+    if (a == MAP_FAILED) {
+        m.n = 0;
+        lkg_set_error("cannot mmap %s: %s", path, strerror(errno));
+        return LKG_ERR_NOMEM;
+    }
+    m.p = (const char *)a;
+    return LKG_OK;
+}
+
+// one line "h r t" (single spaces / tabs between fields, optional trailing \r); returns false on a blank line
+inline bool parse_line(const char *&c, const char *end, int64_t out[3], bool &bad) {
+    while (c < end && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+    if (c >= end || *c == '\n') {
+        if (c < end) ++c;
+        return false;
+    }
+    for (int f = 0; f < 3; ++f) {
+        while (c < end && (*c == ' ' || *c == '\t')) ++c;
+        bool neg = false;
+        if (c < end && *c == '-') {
+            neg = true;
+            ++c;
+        }
+        if (c >= end || *c < '0' || *c > '9') {
+            bad = true;
+            return false;
+        }
+        int64_t v = 0;
+        while (c < end && *c >= '0' && *c <= '9') v = v * 10 + (*c++ - '0');
+        out[f] = neg ? -v : v;
+    }
+    while (c < end && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+    if (c < end && *c != '\n') {
+        bad = true;
+        return false;
+    }
+    if (c < end) ++c;
+    return true;
+}
+}  // namespace
+
+extern "C" int lkg_triples_count(const char *path, int64_t *n_lines) {
+    LKG_REQUIRE(path && n_lines, "lkg_triples_count: null pointer");
+    Mapped m;
+    int rc = map_file(path, m);
+    if (rc != LKG_OK) return rc;
+    int64_t n = 0;
+    const char *c = m.p, *end = m.p + m.n;
+    bool bad = false;
+    int64_t tmp[3];
+    while (c < end) {
+        if (parse_line(c, end, tmp, bad)) ++n;
+        if (bad) {
+            lkg_set_error("%s: malformed line near byte %lld (expected 'h r t')", path, (long long)(c - m.p));
+            return LKG_ERR_INVALID_ARG;
+        }
+    }
+    *n_lines = n;
+    return LKG_OK;
+}
+
+extern "C" int lkg_triples_read(const char *path, int64_t capacity, int64_t *h, int64_t *r, int64_t *t,
+                                int64_t *n_read) {
+    LKG_REQUIRE(path && n_read && (capacity == 0 || (h && r && t)), "lkg_triples_read: null pointer");
+    Mapped m;
+    int rc = map_file(path, m);
+    if (rc != LKG_OK) return rc;
+    int64_t n = 0;
+    const char *c = m.p, *end = m.p + m.n;
+    bool bad = false;
+    int64_t v[3];
+    while (c < end) {
+        if (parse_line(c, end, v, bad)) {
+            if (n >= capacity) {
+                lkg_set_error("%s holds more than the %lld triples the caller sized for", path, (long long)capacity);
+                return LKG_ERR_INVALID_ARG;
+            }
+            h[n] = v[0];
+            r[n] = v[1];
+            t[n] = v[2];
+            ++n;
+        }
+        if (bad) {
+            lkg_set_error("%s: malformed line near byte %lld (expected 'h r t')", path, (long long)(c - m.p));
+            return LKG_ERR_INVALID_ARG;
+        }
+    }
+    *n_read = n;
+    return LKG_OK;
+}
+
+// drop_duplicates(keep='first') of dataloader.py:189: keep[] lists, in input order, the first occurrence of
+// every distinct (h, r, t).
+extern "C" int lkg_triples_dedup(int64_t n, const int64_t *h, const int64_t *r, const int64_t *t, int64_t *keep,
+                                 int64_t *n_keep) {
+    LKG_REQUIRE(n >= 0 && n_keep && (n == 0 || (h && r && t && keep)), "lkg_triples_dedup: bad arguments");
+    std::vector<int64_t> idx((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+        if (h[a] != h[b]) return h[a] < h[b];
+        if (r[a] != r[b]) return r[a] < r[b];
+        if (t[a] != t[b]) return t[a] < t[b];
+        return a < b;
+    });
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t a = idx[i];
+        if (i == 0 || h[a] != h[idx[i - 1]] || r[a] != r[idx[i - 1]] || t[a] != t[idx[i - 1]]) keep[m++] = a;
+    }
+    std::sort(keep, keep + m);
+    *n_keep = m;
+    return LKG_OK;
+}
+
+// Initial attention values  A_in = sum_r norm(A_r)  on the (head, tail)-sorted structure
+// (dataloader.py:449-495).  A_r is the binary adjacency of relation r; with d_r(x) = its ROW sum at x:
+//   kind 0 "random-walk":  D_r^-1 A_r            -> entry (h,t) += 1 / d_r(h)
+//   kind 1 "symmetric"  :  D_r^-1/2 A_r D_r^-1/2 -> entry (h,t) += d_r(h)^-1/2 * d_r(t)^-1/2  (0 when d_r(t) = 0;
+//                          the reference uses the row-sum vector on both sides)
+// Duplicate (h,r,t) raw edges must have been dropped (lkg_triples_dedup), as the loader does.
+extern "C" int lkg_laplacian_f32(int64_t n_entities, int64_t n_raw, int64_t nnz, const int32_t *rowptr,
+                                 const int32_t *col, const int32_t *eptr, const int32_t *rel, int32_t kind,
+                                 float *val_out) {
+    LKG_REQUIRE(n_entities >= 0 && n_raw >= 0 && nnz >= 0 && (kind == 0 || kind == 1), "lkg_laplacian_f32: bad arguments");
+    if (nnz == 0) return LKG_OK;
+    LKG_REQUIRE(rowptr && col && rel && val_out, "lkg_laplacian_f32: null pointer");
+    int32_t n_rel = 0;
+    for (int64_t k = 0; k < n_raw; ++k) n_rel = std::max(n_rel, rel[k] + 1);
+    // out-degree of every (entity, relation) pair
+    std::vector<int32_t> deg;
+    try {
+        deg.assign((size_t)n_entities * n_rel, 0);
+    } catch (...) {
+        lkg_set_error("lkg_laplacian_f32: out of host memory for %lld x %d degree table", (long long)n_entities, n_rel);
+        return LKG_ERR_NOMEM;
+    }
+    for (int64_t i = 0; i < n_entities; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int32_t e0 = eptr ? eptr[j] : j, e1 = eptr ? eptr[j + 1] : j + 1;
+            for (int32_t e = e0; e < e1; ++e) deg[(size_t)i * n_rel + rel[e]]++;
+        }
+    parallel_rows(n_entities, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i)
+            for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+                const int32_t e0 = eptr ? eptr[j] : j, e1 = eptr ? eptr[j + 1] : j + 1;
+                double acc = 0.0;
+                for (int32_t e = e0; e < e1; ++e) {
+                    const double dh = deg[(size_t)i * n_rel + rel[e]];
+                    if (kind == 0) {
+                        acc += 1.0 / dh;
+                    } else {
+                        const double dt = deg[(size_t)col[j] * n_rel + rel[e]];
+                        if (dt > 0) acc += 1.0 / std::sqrt(dh) / std::sqrt(dt);
+                    }
+                }
+                val_out[j] = (float)acc;
+            }
+    });
     return LKG_OK;
 }

@@ -1,0 +1,52 @@
+"""Graph ingestion: "h r t" text -> triples -> KG structure -> the loader's initial A_in.
+
+Replaces, for the hot path's inputs only, DataLoader.load_graph / construct_data / create_adjacency_dict /
+create_laplacian_dict (dataloader.py:186-190, 369-424, 449-495): pandas(engine='python') + iterrows() +
+per-relation scipy matrices become one mmap'd C++ parse, an index sort and a pass over the sorted CSR.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .graph import KGStructure
+
+
+def load_triples(path: str, drop_duplicates: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(h, r, t) int64 arrays in file order, duplicate rows dropped (first kept) like dataloader.py:189."""
+    cnt = np.zeros(1, np.int64)
+    N.call("lkg_triples_count", path.encode(), N.ptr(cnt))
+    n = int(cnt[0])
+    h, r, t = (np.empty(n, np.int64) for _ in range(3))
+    got = np.zeros(1, np.int64)
+    N.call("lkg_triples_read", path.encode(), n, N.ptr(h), N.ptr(r), N.ptr(t), N.ptr(got))
+    assert int(got[0]) == n
+    if drop_duplicates and n:
+        keep = np.empty(n, np.int64)
+        nk = np.zeros(1, np.int64)
+        N.call("lkg_triples_dedup", n, N.ptr(h), N.ptr(r), N.ptr(t), N.ptr(keep), N.ptr(nk))
+        keep = keep[:int(nk[0])]
+        if len(keep) != n:
+            h, r, t = h[keep], r[keep], t[keep]
+    return h, r, t
+
+
+def laplacian_values(g: KGStructure, kind: str = "random-walk") -> torch.Tensor:
+    """fp32[nnz] initial attention values in the structure's entry order (host tensor)."""
+    kinds = {"random-walk": 0, "symmetric": 1}
+    if kind not in kinds:
+        raise NotImplementedError(kind)          # dataloader.py:484
+    val = np.zeros(g.nnz, np.float32)
+    N.call("lkg_laplacian_f32", g.n, g.n_raw, g.nnz, N.ptr(g.host("rowptr")), N.ptr(g.host("col")),
+           N.ptr(g.host("eptr")), N.ptr(g.host("rel")), kinds[kind], N.ptr(val))
+    return torch.from_numpy(val)
+
+
+def initial_a_in(n_entities: int, h, t, r, kind: str = "random-walk") -> torch.Tensor:
+    """The sparse COO N x N tensor DataLoader.A_in holds (dataloader.py:494-495): coalesced, int64 indices."""
+    g = KGStructure.from_triples(n_entities, h, t, r, with_transpose=False)
+    return torch.sparse_coo_tensor(g.coo_indices(), laplacian_values(g, kind), (n_entities, n_entities),
+                                   is_coalesced=True)

@@ -119,3 +119,73 @@ def test_from_coo_keeps_value_order(native):
     a = torch.sparse_coo_tensor(torch.from_numpy(gd["a_indices"]), torch.from_numpy(gd["a_values"]), (n, n)).coalesce()
     g = KGStructure.from_coo(a)
     assert np.array_equal(g.coo_indices().numpy(), gd["a_indices"]) and not g.has_dups
+
+
+# ----------------------------------------------------------------------------- f3 ingestion
+def test_triples_file_roundtrip_and_dedup(native, tmp_path):
+    from literalkg_amd import io
+    gd = load_golden("attention_testslice")           # a slice of the reference's shipped KG file (data)
+    h, t, r = gd["h"], gd["t"], gd["r"]
+    rows = np.stack([h, r, t], 1)
+    rows = np.concatenate([rows, rows[5:25], rows[:3]])            # inject duplicate rows
+    path = tmp_path / "pre_training_train.txt"
+    with open(path, "w") as f:
+        for i, (a, b, c) in enumerate(rows):
+            f.write(f"{a} {b} {c}" + ("\r\n" if i % 7 == 0 else "\n"))
+        f.write("\n")                                               # trailing blank line
+    h2, r2, t2 = io.load_triples(str(path), drop_duplicates=False)
+    assert np.array_equal(np.stack([h2, r2, t2], 1), rows)
+    h3, r3, t3 = io.load_triples(str(path))
+    import pandas as pd
+    want = pd.DataFrame(rows, columns=list("hrt")).drop_duplicates()  # the loader's call (dataloader.py:189)
+    assert np.array_equal(np.stack([h3, r3, t3], 1), want.to_numpy())
+    bad = tmp_path / "bad.txt"
+    bad.write_text("1 2 3\n4 x 6\n")
+    with pytest.raises(native.LkgError, match="malformed"):
+        io.load_triples(str(bad))
+    with pytest.raises(native.LkgError, match="cannot open"):
+        io.load_triples(str(tmp_path / "missing.txt"))
+
+
+@pytest.mark.parametrize("kind", ["random-walk", "symmetric"])
+def test_initial_a_in_matches_loader_restatement(native, kind):
+    from literalkg_amd import io
+    from oracle import literalkg_oracle as O
+    for name in ("encoder_gcn_l1", "attention_testslice"):
+        gd = load_golden(name)
+        n = int(gd["n"])
+        h, t, r = gd["h"], gd["t"], gd["r"]
+        a = io.initial_a_in(n, h, t, r, kind)
+        want = O.laplacian_a_in(n, torch.from_numpy(h), torch.from_numpy(t), torch.from_numpy(r), kind)
+        assert a.is_coalesced() and torch.equal(a.indices(), want.indices())
+        torch.testing.assert_close(a.values(), want.values(), rtol=1e-6, atol=1e-7)
+    gd = load_golden("encoder_gcn_l1")              # and against the scipy-built A_in stored in the fixture
+    a = io.initial_a_in(int(gd["n"]), gd["h"], gd["t"], gd["r"], "random-walk")
+    assert np.array_equal(a.indices().numpy(), gd["a_indices"])
+    np.testing.assert_allclose(a.values().numpy(), gd["a_values"], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        io.initial_a_in(5, np.array([0]), np.array([1]), np.array([0]), "other")
+
+
+REF_KG = "/root/reference/data/Test/pre_training_train.txt"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_KG), reason="reference mount absent (GPU box): build-container check only")
+def test_ingest_the_reference_kg_file(native):
+    """The reference's only complete KG file: parse, drop duplicates and build A_in like its DataLoader
+    (dataloader.py:186-190, 449-495), against pandas / the oracle's restatement."""
+    import pandas as pd
+    from literalkg_amd import io
+    from oracle import literalkg_oracle as O
+    h, r, t = io.load_triples(REF_KG)
+    want = pd.read_csv(REF_KG, sep=" ", names=["h", "r", "t"]).drop_duplicates()
+    assert np.array_equal(np.stack([h, r, t], 1), want.to_numpy())
+    assert len(h) == 217463 and len(set(r.tolist())) == 15          # SURVEY.md section 4
+    n = int(max(h.max(), t.max())) + 1
+    a = io.initial_a_in(n, h, t, r)
+    want_a = O.laplacian_a_in(n, torch.from_numpy(h), torch.from_numpy(t), torch.from_numpy(r))
+    assert torch.equal(a.indices(), want_a.indices())
+    torch.testing.assert_close(a.values(), want_a.values(), rtol=1e-6, atol=1e-7)
+    rs = torch.zeros(n).index_add_(0, a.indices()[0], a.values())
+    assert abs(float(rs[0]) - 9.0) < 1e-5                            # SURVEY.md 3.5-1: row 0 sums to 9
+    assert a._nnz() == len(h) - 33                                   # its 33 duplicate (h,t) pairs are merged
