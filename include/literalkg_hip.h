@@ -167,6 +167,17 @@ int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds
 /* dst[i] = src[perm[i]] for int64 ids                                                              */
 int lkg_gather_i64(int64_t n, const int64_t *src, const int32_t *perm, int64_t *dst, void *stream);
 
+/* f2  device-side batch / negative sampler with the semantics of
+ * DataLoader.generate_kg_batch (dataloader.py:249-330): for each of the n_groups heads one positive
+ * (relation, tail) drawn uniformly from the head's triples and neg_rate negative tails drawn like
+ * random.choice(training_tails), rejecting (tail, relation) positives of the head and repeats inside the
+ * group; h / r / pos_t are repeated neg_rate times.  Outputs are int64[n_groups * neg_rate]; heads must
+ * have at least one triple.  Counter-based RNG: the batch is a pure function of (seed, heads).        */
+int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t seed, const int64_t *heads,
+                        const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                        int64_t nnz, int64_t n_raw, int64_t *out_h, int64_t *out_r, int64_t *out_pos_t,
+                        int64_t *out_neg_t, void *stream);
+
 /* Grouped fp32 MFMA GEMM over segments seg[g]..seg[g+1] (device int32[n_groups+1], no host sync):
  *  mode 1 (rows): C[seg rows,:] = alpha * A[seg rows,:] opB(B + g*stride_b) + beta*C   (A row-major)
  *                 max_seg_len bounds the longest segment (e.g. the batch size).

@@ -147,3 +147,98 @@ extern "C" int lkg_gather_i64(int64_t n, const int64_t *src, const int32_t *perm
     LKG_CHECK_LAUNCH("lkg_gather_i64");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// f2  device-side batch / negative sampler.  Semantics of DataLoader.generate_kg_batch
+// (dataloader.py:249-330) on the sorted KG structure instead of Python dicts:
+//   per sampled head: ONE positive triple drawn uniformly from the head's triples; neg_rate negative tails
+//   drawn uniformly from `training_tails` (= the tail of a uniformly drawn triple, i.e. proportional to
+//   in-degree), rejecting a candidate when (candidate, relation) is a positive of the head or when it
+//   already is one of this head's negatives; h / r / t+ repeated neg_rate times (generate_batch_by_neg_rate).
+// The reference re-draws forever; here a candidate is accepted after MAX_TRIES rejections (cannot happen on
+// graphs with more than neg_rate + out-degree distinct tails).
+namespace {
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Draw {   // counter-based stream: value i of stream (seed, group)
+    unsigned long long key;
+    unsigned ctr;
+    __device__ unsigned long long next() { return mix64(key + 0x9E3779B97F4A7C15ull * (++ctr)); }
+    __device__ long below(long n) { return (long)(next() % (unsigned long long)n); }
+};
+
+// entry holding raw edge k (eptr == nullptr: identity)
+__device__ __forceinline__ int entry_of_raw(const int *eptr, int nnz, int k) {
+    if (!eptr) return k;
+    int lo = 0, hi = nnz;   // last j with eptr[j] <= k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (eptr[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void sample_kg_batch_kernel(long n_groups, int neg_rate, unsigned long long seed,
+                                       const long *__restrict__ heads, const int *__restrict__ rowptr,
+                                       const int *__restrict__ col, const int *__restrict__ eptr,
+                                       const int *__restrict__ rel, int nnz, int n_raw, long *__restrict__ out_h,
+                                       long *__restrict__ out_r, long *__restrict__ out_p, long *__restrict__ out_n) {
+    constexpr int MAX_TRIES = 256;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    Draw d{mix64(seed ^ (0xD1B54A32D192ED03ull * (unsigned long long)(g + 1))), 0u};
+    const long h = heads[g];
+    const int j0 = rowptr[h], j1 = rowptr[h + 1];
+    const int e0 = eptr ? eptr[j0] : j0, e1 = eptr ? eptr[j1] : j1;
+    // positive: uniform over the head's raw triples
+    const int ep = e0 + (int)d.below(e1 - e0);
+    const long r = rel[ep];
+    const long tp = col[entry_of_raw(eptr, nnz, ep)];
+    long *ng = out_n + g * neg_rate;
+    for (int k = 0; k < neg_rate; ++k) {
+        long cand = 0;
+        for (int tries = 0; tries < MAX_TRIES; ++tries) {
+            cand = col[entry_of_raw(eptr, nnz, (int)d.below(n_raw))];
+            bool reject = false;
+            // is (cand, r) a positive of h?  tails are ascending inside the row: binary search, then its relations
+            int lo = j0, hi = j1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (col[mid] < cand) lo = mid + 1; else hi = mid;
+            }
+            if (lo < j1 && col[lo] == cand) {
+                const int f0 = eptr ? eptr[lo] : lo, f1 = eptr ? eptr[lo + 1] : lo + 1;
+                for (int e = f0; e < f1; ++e) reject |= (rel[e] == r);
+            }
+            for (int q = 0; q < k && !reject; ++q) reject = (ng[q] == cand);
+            if (!reject) break;
+        }
+        ng[k] = cand;
+        out_h[g * neg_rate + k] = h;
+        out_r[g * neg_rate + k] = r;
+        out_p[g * neg_rate + k] = tp;
+    }
+}
+}  // namespace
+
+extern "C" int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t seed, const int64_t *heads,
+                                   const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                                   int64_t nnz, int64_t n_raw, int64_t *out_h, int64_t *out_r, int64_t *out_pos_t,
+                                   int64_t *out_neg_t, void *stream) {
+    LKG_REQUIRE(n_groups >= 0 && neg_rate >= 1 && nnz > 0 && n_raw >= nnz && n_raw < INT32_MAX,
+                "lkg_sample_kg_batch: bad sizes");
+    if (n_groups == 0) return LKG_OK;
+    LKG_REQUIRE(heads && rowptr && col && rel && out_h && out_r && out_pos_t && out_neg_t,
+                "lkg_sample_kg_batch: null pointer");
+    hipLaunchKernelGGL(sample_kg_batch_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0,
+                       (hipStream_t)stream, (long)n_groups, neg_rate, (unsigned long long)seed, (const long *)heads,
+                       rowptr, col, eptr, rel, (int)nnz, (int)n_raw, (long *)out_h, (long *)out_r, (long *)out_pos_t,
+                       (long *)out_neg_t);
+    LKG_CHECK_LAUNCH("lkg_sample_kg_batch");
+    return LKG_OK;
+}

@@ -439,6 +439,48 @@ def test_training_trajectory_matches_reference(L, gpu_device, name):
             np.testing.assert_allclose(sd[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+# ----------------------------------------------------------------------------- f2 device-side sampler
+def test_kg_batch_sampler_contract(L, gpu_device):
+    from literalkg_amd.sampler import KGBatchSampler
+    rng = np.random.default_rng(3)
+    n, n_rel = 600, 5
+    h, t, r = rand_graph(rng, n, 7000, n_rel=n_rel, long_rows=[(11, 300)])
+    extra = np.stack([h[:60], (r[:60] + 1) % n_rel, t[:60]], 1)                       # duplicate (h,t) pairs
+    trip = np.unique(np.concatenate([np.stack([h, r, t], 1), extra]), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    assert g.has_dups
+    positives = set(map(tuple, trip.tolist()))
+    k = 7
+    s = KGBatchSampler(g, k)
+    bh, br, bp, bn = (x.cpu().numpy() for x in s.sample(k * 150, seed=42))
+    assert bh.shape == br.shape == bp.shape == bn.shape == (150 * k,)
+    gh, gr, gp = bh.reshape(-1, k), br.reshape(-1, k), bp.reshape(-1, k)
+    assert (gh == gh[:, :1]).all() and (gr == gr[:, :1]).all() and (gp == gp[:, :1]).all()   # repeated K times
+    assert len(set(gh[:, 0].tolist())) == 150                                             # heads without replacement
+    for hh, rr, pp, negs in zip(gh[:, 0], gr[:, 0], gp[:, 0], bn.reshape(-1, k)):
+        assert (hh, rr, pp) in positives
+        assert len(set(negs.tolist())) == k                                               # distinct inside the group
+        assert all((hh, rr, x) not in positives for x in negs)                            # filtered against positives
+    # the batch is a pure function of (torch RNG state for the head draw, seed for the kernel)
+    torch.manual_seed(5)
+    a1 = s.sample(k * 40, seed=7)
+    torch.manual_seed(5)
+    a2 = s.sample(k * 40, seed=7)
+    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
+    torch.manual_seed(5)
+    a3 = s.sample(k * 40, seed=8)
+    assert torch.equal(a1[0], a3[0]) and not torch.equal(a1[3], a3[3])
+    # negatives follow training_tails (in-degree weighted): frequent tails are drawn more often
+    big = s.sample(k * 400, seed=1)[3].cpu().numpy()
+    indeg = np.bincount(t, minlength=n).astype(float)
+    drawn = np.bincount(big, minlength=n).astype(float)
+    assert np.corrcoef(indeg, drawn)[0, 1] > 0.5
+    # more groups than heads: sampling with replacement still fills the batch
+    few = s.sample(k * 50, heads=torch.tensor([11, 12], device=gpu_device), seed=3)
+    assert few[0].numel() == 50 * k and set(few[0].tolist()) <= {11, 12}
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(L, ops, gpu_device):
     """BASELINE config shape (1M entities / 10M edges / D=256): size-independent properties."""
