@@ -249,6 +249,13 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 
+/* f4  one fused Adam step over a dense contiguous tensor (the reference runs dense torch.optim.Adam over
+ * the N x D entity table every step, main_pretraining.py:47,119): torch.optim.Adam's arithmetic,
+ * `step` is the 1-based step count used for the bias corrections; weight_decay is the L2 form.          */
+int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      void *stream);
+
 /* Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32), row-major:
  *   C[m,n] = alpha * sum_k opA(A)[m,k] * opB(B)[k,n] + beta * C[m,n] (+ bias[n])
  * trans_a / trans_b: 0 = stored as written, 1 = stored transposed (A is k x m / B is n x k).

@@ -3,6 +3,7 @@
 // All HBM-bound: each row is read once into registers (one wave per row, 16 bytes per lane per chunk),
 // every statistic is a wave xor-shuffle reduction, every output is written once.
 #include <algorithm>
+#include <cmath>
 
 #include "lkg_common.h"
 
@@ -371,5 +372,56 @@ extern "C" int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx,
     const long rpb = (n + blocks - 1) / blocks;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (long)n, d, x, (long)ldx, out, rpb);
     LKG_CHECK_LAUNCH("lkg_colsum_f32");
+    return LKG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f4  fused Adam step over one dense tensor (the N x D entity table gets a dense gradient every step,
+// SURVEY.md 3.5-5): one pass, 4 reads + 3 writes per element, torch.optim.Adam's arithmetic
+// (bias-corrected, eps added after the sqrt, optional L2 weight decay folded into the gradient).
+namespace {
+__global__ __launch_bounds__(256) void adam_kernel(long n, float *__restrict__ p, const float *__restrict__ g,
+                                                    float *__restrict__ m, float *__restrict__ v, float lr,
+                                                    float beta1, float beta2, float eps, float weight_decay,
+                                                    float bc1, float bc2_sqrt) {
+    const long n4 = n / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float step_size = lr / bc1;
+    auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+        gg = fmaf(weight_decay, pp, gg);
+        mm = fmaf(beta1, mm, (1.f - beta1) * gg);
+        vv = fmaf(beta2, vv, (1.f - beta2) * gg * gg);
+        pp -= step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    };
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i],
+               vv = reinterpret_cast<float4 *>(v)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        upd(pp.x, gg.x, mm.x, vv.x);
+        upd(pp.y, gg.y, mm.y, vv.y);
+        upd(pp.z, gg.z, mm.z, vv.z);
+        upd(pp.w, gg.w, mm.w, vv.w);
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+}
+}  // namespace
+
+extern "C" int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                 void *stream) {
+    LKG_REQUIRE(n >= 0 && step >= 1, "lkg_adam_step_f32: n must be >= 0 and step >= 1");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(param && grad && exp_avg && exp_avg_sq, "lkg_adam_step_f32: null pointer");
+    LKG_REQUIRE(lkg_aligned16(param) && lkg_aligned16(grad) && lkg_aligned16(exp_avg) && lkg_aligned16(exp_avg_sq),
+                "lkg_adam_step_f32: tensors must be 16-byte aligned and contiguous");
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, 256 * 16);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, param, grad,
+                       exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)std::sqrt(bc2));
+    LKG_CHECK_LAUNCH("lkg_adam_step_f32");
     return LKG_OK;
 }

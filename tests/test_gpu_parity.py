@@ -439,6 +439,32 @@ def test_training_trajectory_matches_reference(L, gpu_device, name):
             np.testing.assert_allclose(sd[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+# ----------------------------------------------------------------------------- f4 fused Adam
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch(L, gpu_device, wd):
+    from literalkg_amd.optim import Adam
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(1000, 64), (257,), (3, 5, 7)]
+    ref = [torch.randn(s, generator=gen).requires_grad_(True) for s in shapes]
+    mine = [p.detach().clone().to(gpu_device).requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=3e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=wd)
+    o_mine = Adam(mine, lr=3e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=wd)
+    for step in range(7):
+        for p, q in zip(ref, mine):
+            g = torch.randn(p.shape, generator=gen) * (10.0 ** (step - 3))
+            p.grad, q.grad = g.clone(), g.clone().to(gpu_device)
+        o_ref.step()
+        o_mine.step()
+        for p, q in zip(ref, mine):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+    sd_ref, sd_mine = o_ref.state_dict(), o_mine.state_dict()
+    assert sd_ref["state"][0].keys() == sd_mine["state"][0].keys()            # interchangeable optimizer state
+    torch.testing.assert_close(sd_mine["state"][0]["exp_avg_sq"].cpu(), sd_ref["state"][0]["exp_avg_sq"], rtol=1e-5,
+                               atol=1e-9)
+    o_back = Adam(mine, lr=3e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=wd)
+    o_back.load_state_dict(sd_ref)                                            # torch's Adam state loads into ours
+
+
 # ----------------------------------------------------------------------------- f2 device-side sampler
 def test_kg_batch_sampler_contract(L, gpu_device):
     from literalkg_amd.sampler import KGBatchSampler
