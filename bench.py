@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--sharding", default="features", choices=["features", "rows"],
                     help="N>1: 'features' = column-sharded tables, no collective in the SpMM, all-to-all exchange; "
                          "'rows' = head-row ranges + all-reduce of the entity-gradient table")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="features mode: plain all-to-all after the SpMM instead of per-range sends behind it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and talk over gloo (N>1 code path on a 1-GPU box); "
                          "the numbers of such a run are meaningless")
@@ -172,11 +174,16 @@ def main():
         def step(ev=None):
             if ev is not None:
                 ev[0].record()
-            fs.forward(slab, out=side_slab)                    # all edges, my columns: no collective
-            if ev is not None:
-                ev[1].record()
-            fs.to_row_block(side_slab, out=row_block)          # exchange: rows for the dense part ...
-            fs.to_column_slab(grad_block, out=grad_slab)       # ... and its gradient back to column slabs
+            if args.no_overlap:
+                fs.forward(slab, out=side_slab)                # all edges, my columns: no collective
+                if ev is not None:
+                    ev[1].record()
+                fs.to_row_block(side_slab, out=row_block)      # exchange: rows for the dense part ...
+            else:                                              # ... or the same, sends hidden behind the SpMM
+                fs.forward_to_row_block(slab, side_slab=side_slab, out=row_block)
+                if ev is not None:
+                    ev[1].record()
+            fs.to_column_slab(grad_block, out=grad_slab)       # the dense part's gradient back to column slabs
             if ev is not None:
                 ev[2].record()
             fs.backward(grad_slab, out=grad_table)             # A^T, my columns: no collective, no all-reduce

@@ -119,6 +119,41 @@ class FeatureShardedAggregation:
         g = self.graph
         return self.spmm(g.t_rowptr, g.t_col, self.val_t, grad_slab, g.n, out=out, long_rows=g.long_rows(True))
 
+    def forward_to_row_block(self, slab: torch.Tensor, side_slab: Optional[torch.Tensor] = None,
+                             out: Optional[torch.Tensor] = None):
+        """forward() fused with to_row_block(): the SpMM runs head-row range by head-row range, and as soon as
+        the rows owned by rank j are done their block leaves for rank j (point-to-point, RCCL's stream) while the
+        next range is being aggregated -- the all-to-all hides behind the SpMM except for its last round.
+        Round k computes the rows of rank (rank + k) % G and receives this rank's rows from rank (rank - k) % G.
+        Returns (side_slab [N, D/G], row_block [G, rows_g, D/G])."""
+        g = self.graph
+        if side_slab is None:
+            side_slab = torch.empty((g.n, self.dg), dtype=slab.dtype, device=slab.device)
+        if out is None:
+            out = torch.empty((self.world, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
+        staged = slab.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"   # host-only transport
+        works, host = [], []
+        for k in range(self.world):
+            j, i = (self.rank + k) % self.world, (self.rank - k) % self.world
+            lo, hi = self.cuts[j], self.cuts[j + 1]
+            rows = side_slab[lo:hi]
+            self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=rows, long_rows=g.long_rows(False, lo, hi))
+            if k == 0:
+                out[self.rank].copy_(rows)
+                continue
+            if staged:
+                snd, rcv = rows.cpu(), torch.empty(out[i].shape, dtype=out.dtype)
+                host.append((rcv, i))
+            else:
+                snd, rcv = rows, out[i]
+            works += dist.batch_isend_irecv([dist.P2POp(dist.isend, snd, j, self.group),
+                                             dist.P2POp(dist.irecv, rcv, i, self.group)])
+        for w in works:
+            w.wait()
+        for rcv, i in host:
+            out[i].copy_(rcv)
+        return side_slab, out
+
     def to_row_block(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """N x D/G column slab -> this rank's rows as G column panels, shape [G, rows_g, D/G]
         (panel i = columns of rank i).  One all-to-all."""

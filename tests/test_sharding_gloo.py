@@ -87,6 +87,8 @@ def _feature_worker(rank, world, port, n, d, q):
         want_rows = torch.matmul(a, x)[lo:hi]
         got_rows = torch.cat([block[i] for i in range(world)], dim=1)
         ok &= torch.allclose(got_rows, want_rows, rtol=1e-5, atol=1e-5)
+        side2, block2 = fs.forward_to_row_block(fs.column_slab(x))      # SpMM pipelined with point-to-point sends
+        ok &= torch.equal(side2, side_slab) and torch.equal(block2, block)
         # backward: my rows of grad_side arrive as panels, go back to a column slab, then A^T
         gblock = torch.stack([gside[lo:hi, i * fs.dg:(i + 1) * fs.dg] for i in range(world)]).contiguous()
         gslab = fs.to_column_slab(gblock)
