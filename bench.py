@@ -77,6 +77,51 @@ def cpu_baseline(g, val, n, d, seed):
                       f"{cores} threads"}
 
 
+def whole_path_timings(h, t, r, n, d, dev):
+    """Context numbers for the same graph (SURVEY.md 8d ii-iv), outside the headline metric: the drop-in
+    module's update_att, and one pre_training step (1 gcn layer, D=d, TransR, 2049 triples) forward /
+    forward+backward.  Median of 5 after 2 warm-ups, host-timed around a device sync."""
+    from types import SimpleNamespace
+    import literalkg_amd as L
+    from literalkg_amd.synth import make_batch
+    cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=d, relation_dim=d, scale_gat_dim=None,
+                          use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=1,
+                          conv_dim=d, mess_dropout=0.1, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
+                          pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=300,
+                          use_num_lit=False, use_txt_lit=False, milestone_score=0.5, n_mlp_layers=2, mlp_hidden_dim=64)
+    model = L.LiteralKG(cfg, n, 16).to(dev)
+    hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
+    batch = [torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3)]
+
+    def timed(fn, reps=5):
+        for _ in range(2):
+            fn()
+        ms = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ms))
+
+    rel = list(range(16))
+    upd = timed(lambda: model(hd, td, rd, rel, device=dev, mode="update_att"))
+    model.train()
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        model(*batch, device=dev, mode="pre_training").backward()
+    with torch.no_grad():
+        fwd = timed(lambda: model(*batch, device=dev, mode="pre_training"))
+    step = timed(fwd_bwd)
+    e = len(h)
+    return {"config": f"LiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, same graph",
+            "update_att_ms": upd, "update_att_edges_per_s": e / upd * 1e3,
+            "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
+            "pre_training_step_edges_per_s": e / step * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +132,7 @@ def main():
     ap.add_argument("--edges", type=int, default=None, help="per-GPU edges (default 10M at N=1, 12.5M at N>1)")
     ap.add_argument("--skew", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the whole-path context timings (N=1)")
     ap.add_argument("--chunks", type=int, default=4, help="rows mode: tail-row chunks of the backward (comm overlap)")
     ap.add_argument("--sharding", default="features", choices=["features", "rows"],
                     help="N>1: 'features' = column-sharded tables, no collective in the SpMM, all-to-all exchange; "
@@ -274,6 +320,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, val, n_glob, d, 2022)
+        if world == 1 and not args.no_extra:
+            del side, grad_side, grad_table, shard, ent
+            out["extra"] = whole_path_timings(h, t, r, n_glob, d, dev)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

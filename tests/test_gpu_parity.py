@@ -545,3 +545,31 @@ def test_full_size_properties(L, ops, gpu_device):
         sl = slice(rp[i], rp[i + 1])
         want = (val[sl][:, None] * x1[torch.from_numpy(col[sl]).long().to(gpu_device)]).sum(0)
         assert float((a[i] - want).abs().max()) < 1e-4
+
+
+# ----------------------------------------------------------------------------- C-ABI error convention on the device side
+def test_device_entry_points_reject_bad_arguments(L, ops, gpu_device):
+    from literalkg_amd import _native as N
+    x = torch.zeros(4, 8, device=gpu_device)
+    rp = torch.zeros(5, dtype=torch.int32, device=gpu_device)
+    with pytest.raises(N.LkgError, match="row strides"):
+        N.call("lkg_spmm_csr_f32", 4, 8, N.ptr(rp), None, None, N.ptr(x), 4, N.ptr(x), 8, None, 0, None, 0, 0, None)
+    with pytest.raises(N.LkgError, match="long-row list"):
+        N.call("lkg_spmm_csr_f32", 4, 8, N.ptr(rp), None, None, N.ptr(x), 8, N.ptr(x), 8, None, 0, None, 3, 0, None)
+    with pytest.raises(N.LkgError, match="empty batch"):
+        N.call("lkg_loss_reduce_f32", 0, N.ptr(x), N.ptr(x), 0.0, N.ptr(x), None)
+    with pytest.raises(N.LkgError, match="dropout probability"):
+        ops.act_layernorm(x, torch.ones(8, device=gpu_device), torch.zeros(8, device=gpu_device), drop_p=1.5, seed=1)
+    with pytest.raises(N.LkgError, match="mode must be"):
+        N.call("lkg_grouped_gemm_f32", 3, 1, N.ptr(rp), 4, 0, 0, 4, 8, 8, 1.0, N.ptr(x), 8, N.ptr(x), 8, 0, 0.0,
+               N.ptr(x), 8, 0, None)
+    with pytest.raises(ValueError, match="inner dimensions"):
+        ops.gemm(x, x)
+    with pytest.raises(ValueError, match="embed_dim must equal relation_dim"):
+        g = L.KGStructure.from_triples(4, np.array([0]), np.array([1]), np.array([0]), device=gpu_device)
+        ops.edge_softmax(g, x, torch.zeros(2, 4, device=gpu_device))
+    with pytest.raises(TypeError, match="float32"):
+        ops.gemm(x.double(), x.double().t())
+    # a failed call leaves the library usable
+    y = ops.gemm(x, x, trans_b=True)
+    assert y.shape == (4, 4)
