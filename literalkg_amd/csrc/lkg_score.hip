@@ -9,10 +9,6 @@
 
 namespace {
 
-struct RowSrc {   // where the three entity-side rows of triple b live
-    const float *h, *p, *n;
-};
-
 __device__ __forceinline__ void six_reduce(float &a, float &b, float &c, float &d, float &e, float &f) {
     a = wave_sum(a);
     b = wave_sum(b);

@@ -18,7 +18,6 @@ Fixture families:
   heads_*      f1 fine-tuning loss, calc_score matrix, predict_links
   statedict    key -> shape manifest of the reference's state_dict
 """
-import io
 import json
 import os
 import sys

@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import math
 from types import SimpleNamespace
-from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+from typing import List, Mapping, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F

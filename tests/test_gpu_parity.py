@@ -1,7 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
 generated from the reference.  Tolerances: integer indices bit-exact; fp32 values within 1e-4
 (BASELINE.json north_star), most checks far tighter.  Run with ``-m gpu`` on the MI355X box."""
-import json
 import numpy as np
 import pytest
 import torch
@@ -573,3 +572,72 @@ def test_device_entry_points_reject_bad_arguments(L, ops, gpu_device):
     # a failed call leaves the library usable
     y = ops.gemm(x, x, trans_b=True)
     assert y.shape == (4, 4)
+
+
+# ----------------------------------------------------------------------------- mid-size module vs the oracle (vector paths)
+@pytest.mark.parametrize("agg,layers,dim,gate,scale,scoring", [
+    ("gcn", 2, 128, "mul", 64, "transr"),
+    ("graphsage", 1, 64, "txt", None, "transr"),
+    ("bi-interaction", 2, 64, None, None, "transr"),
+    ("gin", 2, 64, "num", None, "transr"),
+    ("gcn", 1, 256, None, 256, "transe"),
+])
+def test_module_matches_oracle_at_realistic_widths(L, O, gpu_device, agg, layers, dim, gate, scale, scoring):
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e = 20_000, 150_000
+    h, t, r = make_kg(n, e, seed=5)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else (scale or dim * (layers + 1)),
+                        conv_dim=dim, n_conv_layers=layers, aggregation_type=agg, scale_gat_dim=scale,
+                        use_num_lit=gate in ("mul", "num"), use_txt_lit=gate in ("mul", "txt"), txt_lit_dim=300,
+                        mlp_hidden_dim=48, kg_l2loss_lambda=1e-4, device=gpu_device)
+    torch.manual_seed(3)
+    num = torch.rand(n, 2) if cfg.use_num_lit else None
+    txt = torch.randn(n, 300) if cfg.use_txt_lit else None
+    a_in = io.initial_a_in(n, h, t, r)
+    m = L.LiteralKG(cfg, n, 16, a_in, num, txt, scoring=scoring)
+    with torch.no_grad():                      # larger-than-xavier values so every term matters
+        m.entity_embed.weight.mul_(30)
+        m.relation_embed.weight.mul_(3)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
+    m.to(gpu_device).eval()
+    batch = [torch.from_numpy(x) for x in make_batch(n, 200, 3, seed=9)]
+    loss = m(*[b.to(gpu_device) for b in batch], device=gpu_device, mode="pre_training")
+    loss.backward()
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+    want = O.pre_training_loss(p, cfg, a_in, *batch, num=num, txt=txt, form=scoring)
+    want.backward()
+    np.testing.assert_allclose(float(loss), float(want), rtol=1e-4)
+    gat = O.gat_embeddings(params, cfg, a_in, num, txt)
+    torch.testing.assert_close(m.gat_embed.detach().cpu(), gat, rtol=1e-4, atol=1e-4)
+    for k, v in m.named_parameters():
+        if v.grad is not None and k != "A_in":
+            ref = p[k].grad
+            scale_ = float(ref.abs().max()) + 1e-12
+            err = float((v.grad.cpu() - ref).abs().max()) / scale_
+            assert err < 2e-3, (k, err)
+    # update_att on the device, then the refreshed values drive the next forward
+    hd, td, rd = (torch.from_numpy(x).to(gpu_device) for x in (h, t, r))
+    m(hd, td, rd, list(range(16)), device=gpu_device, mode="update_att")
+    ref_a = O.attention_refresh(n, params["entity_embed.weight"], params["relation_embed.weight"],
+                                torch.from_numpy(h), torch.from_numpy(t), torch.from_numpy(r)).coalesce()
+    got_a = m.A_in.data.cpu()
+    assert torch.equal(got_a.indices(), ref_a.indices())
+    torch.testing.assert_close(got_a.values(), ref_a.values(), rtol=1e-4, atol=1e-6)
+
+
+def test_module_moves_and_reloads_on_device(L, O, gpu_device):
+    gd = load_golden("encoder_gcn_l2_scale")
+    m = _build_model(L, gd, torch.device("cpu"), "transr")            # built and loaded on the CPU
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(gpu_device)                                                  # model.to(device), main_pretraining.py:74
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    l1 = float(m(*batch, device=gpu_device, mode="pre_training"))
+    np.testing.assert_allclose(l1, float(gd["loss"]), rtol=1e-5)
+    m2 = L.LiteralKG(golden_cfg(gd), int(gd["n"]), int(gd["n_rel"])).to(gpu_device).eval()
+    m2.load_state_dict(sd)                                            # CPU checkpoint into a device module
+    assert m2.A_in.is_sparse and m2.A_in.device.type == "cuda"
+    np.testing.assert_allclose(float(m2(*batch, device=gpu_device, mode="pre_training")), l1, rtol=1e-6)
+    m2.A_in.data._values().mul_(2.0)                                  # in-place edit of the values is picked up
+    l3 = float(m2(*batch, device=gpu_device, mode="pre_training"))
+    assert abs(l3 - l1) > 1e-6

@@ -3,7 +3,6 @@ mode dispatch) and the no-CPU-fallback guarantee."""
 import json
 import os
 
-import numpy as np
 import pytest
 import torch
 

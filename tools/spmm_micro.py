@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of lkg_spmm_csr_f32 on the BASELINE graph shapes (GPU box only; not part of the tests).
    python tools/spmm_micro.py [--dim 256] [--skew zipf]"""
-import argparse, os, sys, time
+import argparse, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge

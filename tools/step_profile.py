@@ -3,7 +3,7 @@
    python tools/step_profile.py --config c2|c3 [--agg gcn]"""
 import argparse, os, sys, time
 from types import SimpleNamespace
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.build()
