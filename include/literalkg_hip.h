@@ -106,6 +106,20 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
                      const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                      int32_t long_thresh, void *stream);
 
+/* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
+ * layer only needs the rows its consumers read.  lkg_csr_extract_rows copies the entries of the (sorted,
+ * int64) rows sel_rows into a compact CSR whose offsets out_rowptr int32[n_sel+1] the caller has already
+ * computed (exclusive scan of the row lengths); col keeps the ORIGINAL ids.
+ * lkg_spmm_csr_scatter_bwd_f32 is the backward of out = A_sub @ x for such a small sub-CSR without
+ * building its transpose every step: g_x[col[j],:] += val[j] * g_out[row,:] (f32 atomics; g_x is
+ * zero-initialised by the caller).                                                                */
+int lkg_csr_extract_rows(int64_t n_sel, const int64_t *sel_rows, const int32_t *rowptr, const int32_t *col,
+                         const float *val, const int32_t *out_rowptr, int32_t *out_col, float *out_val,
+                         void *stream);
+int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                                 const float *val, const float *g_out, int64_t ldg, float *g_x,
+                                 int64_t ldx, void *stream);
+
 /* K1+K2  attention refresh, fused: per stored entry
  *     v = sum over its raw edges e of  sum_d ent[t,d] * tanh(ent[h,d] + relemb[rel[e],d])
  * then softmax of v over the stored entries of each head row.

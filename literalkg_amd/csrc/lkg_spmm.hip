@@ -256,3 +256,69 @@ extern "C" int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src,
     LKG_CHECK_LAUNCH("lkg_permute_f32");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Batch-pruned step (exact; see literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so
+// layer k is only evaluated on the rows its consumers need.  Two helpers on the same CSR:
+//   lkg_csr_extract_rows       copy the entries (col, val) of a sorted list of rows into a compact CSR
+//   lkg_spmm_csr_scatter_bwd   backward of out = A_sub @ x for such a (small) sub-CSR without building its
+//                              transpose every step:  g_x[col[j],:] += val[j] * g_out[row,:]  (f32 atomics,
+//                              one 16-B-per-lane row segment per wave-instruction)
+namespace {
+__global__ __launch_bounds__(256) void extract_rows_kernel(long n_sel, const long *__restrict__ sel,
+                                                            const int *__restrict__ rowptr,
+                                                            const int *__restrict__ col, const float *__restrict__ val,
+                                                            const int *__restrict__ out_rowptr,
+                                                            int *__restrict__ out_col, float *__restrict__ out_val) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_sel) return;
+    const int src = rowptr[sel[i]], cnt = rowptr[sel[i] + 1] - src, dst = out_rowptr[i];
+    for (int j = lane; j < cnt; j += 64) {
+        out_col[dst + j] = col[src + j];
+        out_val[dst + j] = val[src + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void spmm_scatter_bwd_kernel(long n_rows, int d, const int *__restrict__ rowptr,
+                                                                const int *__restrict__ col,
+                                                                const float *__restrict__ val,
+                                                                const float *__restrict__ g_out, long ldg,
+                                                                float *__restrict__ g_x, long ldx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int start = rowptr[row], end = rowptr[row + 1];
+    for (int c0 = 0; c0 < d; c0 += 64) {
+        const int c = c0 + lane;
+        const float g = c < d ? g_out[row * ldg + c] : 0.f;
+        for (int j = start; j < end; ++j)
+            if (c < d) atomicAdd(g_x + (long)col[j] * ldx + c, val[j] * g);
+    }
+}
+}  // namespace
+
+extern "C" int lkg_csr_extract_rows(int64_t n_sel, const int64_t *sel_rows, const int32_t *rowptr, const int32_t *col,
+                                    const float *val, const int32_t *out_rowptr, int32_t *out_col, float *out_val,
+                                    void *stream) {
+    LKG_REQUIRE(n_sel >= 0, "lkg_csr_extract_rows: negative row count");
+    if (n_sel == 0) return LKG_OK;
+    LKG_REQUIRE(sel_rows && rowptr && col && val && out_rowptr && out_col && out_val,
+                "lkg_csr_extract_rows: null pointer");
+    hipLaunchKernelGGL(extract_rows_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n_sel, (const long *)sel_rows, rowptr, col, val, out_rowptr, out_col, out_val);
+    LKG_CHECK_LAUNCH("lkg_csr_extract_rows");
+    return LKG_OK;
+}
+
+extern "C" int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                                            const float *val, const float *g_out, int64_t ldg, float *g_x,
+                                            int64_t ldx, void *stream) {
+    LKG_REQUIRE(n_rows >= 0 && d > 0 && ldg >= d && ldx >= d, "lkg_spmm_csr_scatter_bwd_f32: bad sizes");
+    if (n_rows == 0) return LKG_OK;
+    LKG_REQUIRE(rowptr && col && val && g_out && g_x, "lkg_spmm_csr_scatter_bwd_f32: null pointer");
+    hipLaunchKernelGGL(spmm_scatter_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n_rows, d, rowptr, col, val, g_out, (long)ldg, g_x, (long)ldx);
+    LKG_CHECK_LAUNCH("lkg_spmm_csr_scatter_bwd_f32");
+    return LKG_OK;
+}

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, pruned
 from .gate import Gate, GateMul
 from .graph import KGStructure
 
@@ -222,6 +222,10 @@ class LiteralKG(nn.Module):
         self.A_in = nn.Parameter(empty, requires_grad=False)
         if A_in is not None:
             self.A_in.data = A_in
+        # opt-in: evaluate every layer only on the rows the batch needs (exact, see pruned.py); then
+        # self.gat_embed holds the rows self.gat_rows instead of all N
+        self.prune_to_batch = bool(getattr(args, "prune_to_batch", False))
+        self.gat_rows = None
         self._att: Optional[AttentionCSR] = None
         self._att_key = None
         self._triple_graph = None
@@ -245,20 +249,27 @@ class LiteralKG(nn.Module):
         return self._att
 
     # ------------------------------------------------------------------ a6/a7 encoder
-    def gate_embeddings(self):
-        ent = self.entity_embed.weight
+    def _gate(self, ent, num, txt):
+        a = self.args
+        if a.use_num_lit and a.use_txt_lit:
+            return self.emb_mul_lit(ent, num, txt)
+        if a.use_num_lit:
+            return self.emb_num_lit(ent, num)
+        if a.use_txt_lit:
+            return self.emb_txt_lit(ent, txt)
+        return ent
+
+    def _literals(self):
         a = self.args
         if a.use_num_lit:
             self.numerical_literals_embed = self.numerical_literals_embed.to(self.device)
         if a.use_txt_lit:
             self.text_literals_embed = self.text_literals_embed.to(self.device)
-        if a.use_num_lit and a.use_txt_lit:
-            return self.emb_mul_lit(ent, self.numerical_literals_embed, self.text_literals_embed)
-        if a.use_num_lit:
-            return self.emb_num_lit(ent, self.numerical_literals_embed)
-        if a.use_txt_lit:
-            return self.emb_txt_lit(ent, self.text_literals_embed)
-        return ent
+        return (self.numerical_literals_embed if a.use_num_lit else None,
+                self.text_literals_embed if a.use_txt_lit else None)
+
+    def gate_embeddings(self):
+        return self._gate(self.entity_embed.weight, *self._literals())
 
     def gat_embeddings(self):
         att = self._attention()
@@ -272,9 +283,47 @@ class LiteralKG(nn.Module):
             return F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
         return cat
 
+    def _can_prune(self) -> bool:
+        # gin sums earlier layers' outputs row by row (model.py:151-158): not wired for compact rows
+        return self.prune_to_batch and self.aggregation_type != "gin"
+
+    def gat_embeddings_for(self, ids: torch.Tensor):
+        """Rows `unique(ids)` of gat_embeddings(), computed on the batch's L-hop frontier only (pruned.py).
+        Returns (compact table, BatchSubgraph)."""
+        att = self._attention()
+        sub = pruned.build_batch_subgraph(att.graph, att.val, ids, self.n_layers)
+        top = self.n_layers
+        num, txt = self._literals()
+        r0 = sub.rows[0]
+        g0 = self._gate(pruned.gather_rows(self.entity_embed.weight, r0),
+                        ops.gather_rows(num, r0) if num is not None else None,
+                        ops.gather_rows(txt, r0) if txt is not None else None)
+        kept = [pruned.gather_rows(g0, sub.rows_in(top, 0))]
+        cur = g0
+        for k, layer in enumerate(self.aggregator_layers, start=1):
+            sl = sub.layers[k]
+            ego = pruned.gather_rows(cur, sl.self_pos)
+            h0 = pruned.gather_rows(g0, sub.rows_in(k, 0)) if layer.use_residual else g0
+            cur = layer(ego, pruned.CompactAttention(sl, cur), [h0], self.lamda, self.alpha, k)
+            norm = layer.last_normalized
+            kept.append(norm if k == top else pruned.gather_rows(norm, sub.rows_in(top, k)))
+        cat = torch.cat(kept, dim=1)
+        if self.scale_gat_dim is not None:
+            cat = F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
+        return cat, sub
+
+    def _embeddings_and_ids(self, *id_lists):
+        """(table, relabelled ids): the full table with the ids as given, or the pruned table with positions."""
+        if not self._can_prune():
+            self.gat_rows = None
+            return self.gat_embeddings(), id_lists
+        table, sub = self.gat_embeddings_for(torch.cat([i.reshape(-1) for i in id_lists]))
+        self.gat_rows = sub.rows[-1]
+        return table, tuple(sub.positions(i) for i in id_lists)
+
     # ------------------------------------------------------------------ a8/a9 loss
     def calc_triplet_loss(self, h, r, pos_t, neg_t):
-        self.gat_embed = self.gat_embeddings()
+        self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         keep = self.last_scores if not self.training else None
         if self.scoring == "transr":
             return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
@@ -311,7 +360,7 @@ class LiteralKG(nn.Module):
 
     # ------------------------------------------------------------------ f1 heads
     def calc_score(self, head_ids, tail_ids):
-        emb = self.gat_embeddings()
+        emb, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
         return ops.gemm(ops.gather_rows(emb.detach(), head_ids), ops.gather_rows(emb.detach(), tail_ids),
                         trans_b=True)
 
@@ -337,5 +386,6 @@ class LiteralKG(nn.Module):
 
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
         """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
-        self.gat_embed = self.gat_embeddings()
+        self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
+            head_ids, tail_pos_ids, tail_neg_ids)
         return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda)

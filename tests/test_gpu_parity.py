@@ -641,3 +641,68 @@ def test_module_moves_and_reloads_on_device(L, O, gpu_device):
     m2.A_in.data._values().mul_(2.0)                                  # in-place edit of the values is picked up
     l3 = float(m2(*batch, device=gpu_device, mode="pre_training"))
     assert abs(l3 - l1) > 1e-6
+
+
+# ----------------------------------------------------------------------------- batch-pruned step == dense step
+@pytest.mark.parametrize("name", ["encoder_gcn_l1", "encoder_gcn_l2_scale", "encoder_gcn_l2_res_wide", "encoder_sage_l2",
+                                  "encoder_sage_l1_res", "encoder_bi_l2", "encoder_bi_l1_res", "encoder_gcn_l1_gatemul",
+                                  "encoder_gcn_l2_gatenum", "encoder_gcn_l1_gatetxt_scale", "transe_gcn_l2_gatemul"])
+def test_pruned_step_matches_reference_fixture(L, gpu_device, name):
+    """prune_to_batch evaluates each layer on the batch's L-hop frontier only; loss, scores and every
+    parameter gradient must equal what the REFERENCE produced with its full-graph recompute."""
+    gd = load_golden(name)
+    form = str(gd["form"])
+    m = _build_model(L, gd, gpu_device, form)
+    m.prune_to_batch = True
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    assert m.gat_rows is not None and m.gat_embed.shape[0] == m.gat_rows.numel() < int(gd["n"])
+    np.testing.assert_allclose(m.gat_embed.detach().cpu().numpy(), gd["gat"][m.gat_rows.cpu().numpy()], rtol=TOL,
+                               atol=TOL)
+    np.testing.assert_allclose(m.last_scores["pos"].cpu().numpy(), gd["pos"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
+    loss.backward()
+    grads = {k: v.grad for k, v in m.named_parameters() if v.grad is not None}
+    for k, want in gd.items():
+        if k.startswith("g/"):
+            assert k[2:] in grads, k
+            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+    if form == "transr":
+        hid, tid = torch.from_numpy(gd["score_heads"]).to(gpu_device), torch.from_numpy(gd["score_tails"]).to(gpu_device)
+        with torch.no_grad():
+            np.testing.assert_allclose(m.calc_score(hid, tid).cpu().numpy(), gd["score"], rtol=TOL, atol=TOL)
+        m.zero_grad()
+        ft = m(batch[0], batch[2], batch[3], device=gpu_device, mode="fine_tuning")
+        np.testing.assert_allclose(float(ft.detach()), float(gd["ft_loss"]), rtol=1e-5)
+        ft.backward()
+        np.testing.assert_allclose(m.entity_embed.weight.grad.cpu().numpy(), gd["ft_g/entity_embed.weight"],
+                                   rtol=2e-3, atol=2e-6)
+
+
+def test_pruned_trajectory_matches_reference(L, gpu_device):
+    gd = load_golden("trajectory_gcn_l2_gatemul_scale")
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.prune_to_batch = True
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=float(gd["lr"]))
+    h, t, r = (torch.from_numpy(gd[k]).to(gpu_device) for k in "htr")
+    for step, b in enumerate(gd["batches"]):
+        opt.zero_grad()
+        loss = m(*[torch.from_numpy(x).to(gpu_device) for x in b], device=gpu_device, mode="pre_training")
+        loss.backward()
+        opt.step()
+        np.testing.assert_allclose(loss.item(), gd["losses"][step], rtol=1e-4, err_msg=f"step {step}")
+        if step == int(gd["refresh_after"]):
+            m(h, t, r, list(range(int(gd["n_rel"]))), device=gpu_device, mode="update_att")
+    np.testing.assert_allclose(m.entity_embed.weight.detach().cpu().numpy(), gd["f/entity_embed.weight"], rtol=2e-3,
+                               atol=2e-5)
+
+
+def test_gin_ignores_prune_flag(L, gpu_device):
+    gd = load_golden("encoder_gin_l2")
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.prune_to_batch = True
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    assert m.gat_rows is None and m.gat_embed.shape[0] == int(gd["n"])
+    np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
