@@ -15,6 +15,8 @@ ap.add_argument("--config", default="c2")
 ap.add_argument("--agg", default="gcn")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--scoring", default="transr")
+ap.add_argument("--prune", action="store_true")
+ap.add_argument("--fused-adam", action="store_true")
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--e", type=int, default=10_000_000)
 args = ap.parse_args()
@@ -35,6 +37,7 @@ num = torch.rand(n, 2, device=dev) if cfg.use_num_lit else None
 txt = torch.randn(n, 300, device=dev) if cfg.use_txt_lit else None
 model = L.LiteralKG(cfg, n, 16, None, num, txt, scoring=args.scoring).to(dev)
 model.eval()
+model.prune_to_batch = args.prune
 hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
 def sync_time(fn, iters=args.iters):
     fn(); torch.cuda.synchronize()
@@ -47,7 +50,11 @@ model(hd, td, rd, list(range(16)), device=dev, mode="update_att"); torch.cuda.sy
 print(f"first update_att incl. host CSR build: {(time.perf_counter()-t0)*1e3:.0f} ms")
 ua = sync_time(lambda: model(hd, td, rd, list(range(16)), device=dev, mode="update_att"))
 bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3))
-opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+if args.fused_adam:
+    from literalkg_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=1e-4)
+else:
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 def fwd():
     return model(bh, br, bp, bn, device=dev, mode="pre_training")
 def step():
@@ -61,5 +68,5 @@ f = sync_time(fwd)
 s = sync_time(step)
 so = sync_time(step_opt)
 L_ = cfg.n_conv_layers
-print(f"{args.config} {args.agg} {args.scoring}: update_att {ua:.2f} ms ({e/ua/1e6:.2f} G edges/s) | fwd(no grad) {f_ng:.2f} | fwd {f:.2f} | fwd+bwd {s:.2f} ms "
+print(f"{args.config} {args.agg} {args.scoring} prune={args.prune} fused_adam={args.fused_adam}: update_att {ua:.2f} ms ({e/ua/1e6:.2f} G edges/s) | fwd(no grad) {f_ng:.2f} | fwd {f:.2f} | fwd+bwd {s:.2f} ms "
       f"({e*L_/s/1e6:.2f} G edges/s) | +Adam {so:.2f} ms | mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
