@@ -47,16 +47,22 @@ struct RowRegs {
     __device__ __forceinline__ bool live(int k, int d, int lane) const { return (lane + 64 * (k / W)) * W + (k % W) < d; }
 };
 
-// Counter-based dropout mask: keep(seed, element index) is a pure function (splitmix64 finaliser), so the
-// backward regenerates the mask instead of storing it.  torch's Philox stream cannot be reproduced from
-// outside ATen, so training-mode parity with the reference is statistical.
-__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-    unsigned long long z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
+// Counter-based dropout mask: keep(seed, row, col) is a pure function (two rounds of the murmur3 32-bit
+// finaliser), so the backward regenerates the mask instead of storing it.  torch's Philox stream cannot be
+// reproduced from outside ATen, so training-mode parity with the reference is statistical.
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ unsigned drop_row_key(unsigned long long seed, unsigned long long row) {
+    return fmix32((unsigned)seed ^ fmix32((unsigned)row * 0x9E3779B1u + (unsigned)(row >> 32) + (unsigned)(seed >> 32)));
+}
+__device__ __forceinline__ float drop_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
+    const unsigned h = fmix32(row_key ^ (col * 0x27D4EB2Fu + 0x165667B1u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
 }
 
 template <int W, int CPL>
@@ -92,12 +98,13 @@ __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const fl
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
     float nn = 0.f;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const unsigned rkey = drop_row_key(seed, (unsigned long long)row);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float o = (a.v[k] - mean) * rstd * g.v[k] + b.v[k];
         if (drop_p > 0.f) {
             const int e = (lane + 64 * (k / W)) * W + (k % W);
-            o *= drop_scale(seed, (unsigned long long)row * d + e, drop_p, inv_keep);
+            o *= drop_scale(rkey, (unsigned)e, drop_p, inv_keep);
         }
         a.v[k] = o;
         nn += a.live(k, d, lane) ? o * o : 0.f;
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta,
                                                           float drop_p, unsigned long long seed) {
     constexpr int K = CPL * W;
+    __shared__ float red_g[3][K][64], red_b[3][K][64];
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
@@ -172,10 +180,11 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
         }
         if (drop_p > 0.f) {   // y (and g_y / g_yn) refer to the masked output: route G through the mask
             const float inv_keep = 1.f / (1.f - drop_p);
+            const unsigned rkey = drop_row_key(seed, (unsigned long long)row);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int e = (lane + 64 * (k / W)) * W + (k % W);
-                G.v[k] *= drop_scale(seed, (unsigned long long)row * d + e, drop_p, inv_keep);
+                G.v[k] *= drop_scale(rkey, (unsigned)e, drop_p, inv_keep);
             }
         }
         const float mean = save_mean[row], rstd = save_rstd[row];
@@ -203,45 +212,111 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
         }
         zz.store(g_z + row * ldgz, d, lane);
     }
+    // the four waves of the workgroup meet in LDS first: one atomic per workgroup per column (every workgroup
+    // hits the same 2*d addresses, and contended float atomics are an order of magnitude slower)
+    const int w = threadIdx.x >> 6;
+    if (w > 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int e = (lane + 64 * (k / W)) * W + (k % W);
-        if (e < d) {
-            atomicAdd(g_gamma + e, acc_g[k]);
-            atomicAdd(g_beta + e, acc_b[k]);
+        for (int k = 0; k < K; ++k) {
+            red_g[w - 1][k][lane] = acc_g[k];
+            red_b[w - 1][k][lane] = acc_b[k];
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = (lane + 64 * (k / W)) * W + (k % W);
+            if (e < d) {
+                atomicAdd(g_gamma + e, acc_g[k] + red_g[0][k][lane] + red_g[1][k][lane] + red_g[2][k][lane]);
+                atomicAdd(g_beta + e, acc_b[k] + red_b[0][k][lane] + red_b[1][k][lane] + red_b[2][k][lane]);
+            }
         }
     }
 }
 
-__global__ void gate_blend_fwd_kernel(long n, int d, const float *__restrict__ x, long ldx,
-                                      const float *__restrict__ gpre, long ldg, const float *__restrict__ zpre,
-                                      long ldz, float *__restrict__ out, long ldo) {
-    const long total = n * d;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / d;
-        const int c = (int)(i - r * d);
-        const float s = sigmoidf_(zpre[r * ldz + c]);
-        const float tg = tanhf(gpre[r * ldg + c]);
-        out[r * ldo + c] = (1.f - s) * x[r * ldx + c] + s * tg;
-    }
+// Literal-gate blend: rows are walked by groups of TPR = 2^k threads (TPR * W >= d when possible), so the
+// (row, column) of an element needs shifts only and every access is a 16-byte one when rows are aligned.
+template <int W>
+__global__ __launch_bounds__(256) void gate_blend_fwd_kernel(long n, int d, int log_tpr, const float *__restrict__ x,
+                                                              long ldx, const float *__restrict__ gpre, long ldg,
+                                                              const float *__restrict__ zpre, long ldz,
+                                                              float *__restrict__ out, long ldo) {
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c0 = (threadIdx.x & (tpr - 1)) * W;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+        for (int c = c0; c < d; c += tpr * W) {
+            float xv[W], gv[W], zv[W], ov[W];
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+                *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(gpre + r * ldg + c);
+                *reinterpret_cast<float4 *>(zv) = *reinterpret_cast<const float4 *>(zpre + r * ldz + c);
+            } else {
+                xv[0] = x[r * ldx + c];
+                gv[0] = gpre[r * ldg + c];
+                zv[0] = zpre[r * ldz + c];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float s = sigmoid_fast(zv[k]);
+                ov[k] = (1.f - s) * xv[k] + s * tanh_fast(gv[k]);
+            }
+            if constexpr (W == 4)
+                *reinterpret_cast<float4 *>(out + r * ldo + c) = *reinterpret_cast<float4 *>(ov);
+            else
+                out[r * ldo + c] = ov[0];
+        }
 }
 
-__global__ void gate_blend_bwd_kernel(long n, int d, const float *__restrict__ x, long ldx,
-                                      const float *__restrict__ gpre, long ldg, const float *__restrict__ zpre,
-                                      long ldz, const float *__restrict__ g_out, long ldgo, float *__restrict__ g_x,
-                                      long ldgx, float *__restrict__ g_gpre, long ldgg, float *__restrict__ g_zpre,
-                                      long ldgz) {
-    const long total = n * d;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / d;
-        const int c = (int)(i - r * d);
-        const float s = sigmoidf_(zpre[r * ldz + c]);
-        const float tg = tanhf(gpre[r * ldg + c]);
-        const float go = g_out[r * ldgo + c];
-        g_x[r * ldgx + c] = go * (1.f - s);
-        g_gpre[r * ldgg + c] = go * s * (1.f - tg * tg);
-        g_zpre[r * ldgz + c] = go * (tg - x[r * ldx + c]) * s * (1.f - s);
-    }
+template <int W>
+__global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int log_tpr, const float *__restrict__ x,
+                                                              long ldx, const float *__restrict__ gpre, long ldg,
+                                                              const float *__restrict__ zpre, long ldz,
+                                                              const float *__restrict__ g_out, long ldgo,
+                                                              float *__restrict__ g_x, long ldgx,
+                                                              float *__restrict__ g_gpre, long ldgg,
+                                                              float *__restrict__ g_zpre, long ldgz) {
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c0 = (threadIdx.x & (tpr - 1)) * W;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+        for (int c = c0; c < d; c += tpr * W) {
+            float xv[W], gv[W], zv[W], go[W], ox[W], og[W], oz[W];
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+                *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(gpre + r * ldg + c);
+                *reinterpret_cast<float4 *>(zv) = *reinterpret_cast<const float4 *>(zpre + r * ldz + c);
+                *reinterpret_cast<float4 *>(go) = *reinterpret_cast<const float4 *>(g_out + r * ldgo + c);
+            } else {
+                xv[0] = x[r * ldx + c];
+                gv[0] = gpre[r * ldg + c];
+                zv[0] = zpre[r * ldz + c];
+                go[0] = g_out[r * ldgo + c];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float s = sigmoid_fast(zv[k]);
+                const float tg = tanh_fast(gv[k]);
+                ox[k] = go[k] * (1.f - s);
+                og[k] = go[k] * s * (1.f - tg * tg);
+                oz[k] = go[k] * (tg - xv[k]) * s * (1.f - s);
+            }
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(g_x + r * ldgx + c) = *reinterpret_cast<float4 *>(ox);
+                *reinterpret_cast<float4 *>(g_gpre + r * ldgg + c) = *reinterpret_cast<float4 *>(og);
+                *reinterpret_cast<float4 *>(g_zpre + r * ldgz + c) = *reinterpret_cast<float4 *>(oz);
+            } else {
+                g_x[r * ldgx + c] = ox[0];
+                g_gpre[r * ldgg + c] = og[0];
+                g_zpre[r * ldgz + c] = oz[0];
+            }
+        }
+}
+
+// threads per row (log2) for a row of `units` access units
+inline int log_threads_per_row(int units) {
+    int l = 0;
+    while ((1 << l) < units && l < 8) ++l;
+    return l;
 }
 
 template <int W>
@@ -310,7 +385,7 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                      (!g_yn || (ldgyn % 4 == 0 && ldy % 4 == 0)) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
                      lkg_aligned16(gamma) && (!g_y || lkg_aligned16(g_y)) &&
                      (!g_yn || (lkg_aligned16(g_yn) && lkg_aligned16(y)));
-    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 2048));
+    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 1024));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
                      (unsigned long long)seed);
@@ -324,9 +399,16 @@ extern "C" int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int6
     LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldg >= d && ldz >= d && ldo >= d, "lkg_gate_blend_fwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
     LKG_REQUIRE(x && gpre && zpre && out, "lkg_gate_blend_fwd_f32: null pointer");
-    const int64_t blocks = std::min<int64_t>((n * d + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(gate_blend_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, x,
-                       (long)ldx, gpre, (long)ldg, zpre, (long)ldz, out, (long)ldo);
+    const bool vec = d % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && lkg_aligned16(x) &&
+                     lkg_aligned16(gpre) && lkg_aligned16(zpre) && lkg_aligned16(out);
+    const int lt = log_threads_per_row(vec ? d / 4 : d);
+    const int64_t blocks = std::min<int64_t>((n + (256 >> lt) - 1) / (256 >> lt), 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(gate_blend_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
+                           d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, out, (long)ldo);
+    else
+        hipLaunchKernelGGL(gate_blend_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
+                           d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, out, (long)ldo);
     LKG_CHECK_LAUNCH("lkg_gate_blend_fwd_f32");
     return LKG_OK;
 }
@@ -339,10 +421,19 @@ extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int6
                 "lkg_gate_blend_bwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
     LKG_REQUIRE(x && gpre && zpre && g_out && g_x && g_gpre && g_zpre, "lkg_gate_blend_bwd_f32: null pointer");
-    const int64_t blocks = std::min<int64_t>((n * d + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(gate_blend_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, x,
-                       (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx, g_gpre,
-                       (long)ldgg, g_zpre, (long)ldgz);
+    const bool vec = d % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldgo % 4 == 0 && ldgx % 4 == 0 &&
+                     ldgg % 4 == 0 && ldgz % 4 == 0 && lkg_aligned16(x) && lkg_aligned16(gpre) && lkg_aligned16(zpre) &&
+                     lkg_aligned16(g_out) && lkg_aligned16(g_x) && lkg_aligned16(g_gpre) && lkg_aligned16(g_zpre);
+    const int lt = log_threads_per_row(vec ? d / 4 : d);
+    const int64_t blocks = std::min<int64_t>((n + (256 >> lt) - 1) / (256 >> lt), 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(gate_blend_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
+                           d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz);
+    else
+        hipLaunchKernelGGL(gate_blend_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
+                           d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz);
     LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_f32");
     return LKG_OK;
 }
@@ -352,9 +443,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(long n, int d, const float 
                                                       float *__restrict__ out, long rows_per_block) {
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float s = 0.f;
-        for (long r = r0; r < r1; ++r) s += x[r * ldx + c];
-        atomicAdd(out + c, s);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four rows in flight per thread
+        long r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            s0 += x[r * ldx + c];
+            s1 += x[(r + 1) * ldx + c];
+            s2 += x[(r + 2) * ldx + c];
+            s3 += x[(r + 3) * ldx + c];
+        }
+        for (; r < r1; ++r) s0 += x[r * ldx + c];
+        atomicAdd(out + c, (s0 + s1) + (s2 + s3));
     }
 }
 }  // namespace
