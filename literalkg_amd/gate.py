@@ -24,7 +24,7 @@ class GateMul(nn.Module):
         self.gate_txt_lit = nn.Linear(txt_lit_size, emb_size, bias=False)
         self.gate_bias = nn.Parameter(torch.zeros(emb_size))
 
-    def forward(self, x_ent, x_lit_num, x_lit_txt):
+    def forward(self, x_ent, x_lit_num, x_lit_txt, out=None):
         d, n = self.emb_size, self.num_lit_size
         wg = self.g.weight
         gpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt), (wg[:, :d], wg[:, d:d + n], wg[:, d + n:]),
@@ -32,7 +32,7 @@ class GateMul(nn.Module):
         zpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt),
                                 (self.gate_ent.weight, self.gate_num_lit.weight, self.gate_txt_lit.weight),
                                 self.gate_bias)
-        return ops.gate_blend(x_ent, gpre, zpre)
+        return ops.gate_blend(x_ent, gpre, zpre, out)
 
 
 class Gate(nn.Module):
@@ -46,9 +46,9 @@ class Gate(nn.Module):
         self.gate_lit = nn.Linear(lit_size, emb_size, bias=False)
         self.gate_bias = nn.Parameter(torch.zeros(emb_size))
 
-    def forward(self, x_ent, x_lit):
+    def forward(self, x_ent, x_lit, out=None):
         d = self.emb_size
         wg = self.g.weight
         gpre = ops.multi_linear((x_ent, x_lit), (wg[:, :d], wg[:, d:]), self.g.bias)
         zpre = ops.multi_linear((x_ent, x_lit), (self.gate_ent.weight, self.gate_lit.weight), self.gate_bias)
-        return ops.gate_blend(x_ent, gpre, zpre)
+        return ops.gate_blend(x_ent, gpre, zpre, out)

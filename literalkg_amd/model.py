@@ -88,6 +88,7 @@ class Aggregator(nn.Module):
                 self.out_linear = nn.Linear(hid, out_dim)
                 self.mlp_layer_norms = nn.ModuleList(nn.LayerNorm(hid) for _ in range(self.num_layers - 1))
         self.last_normalized = None
+        self.norm_out = None   # set by the encoder: the concat-buffer slice the normalised copy goes to
 
     # (1-a) hi + a W0 h0, then @ ((1-b) + b W)   -- (1-b) lands on every entry of W (model.py:96)
     def residual_connection(self, hi, h0, lamda, alpha, l):
@@ -113,7 +114,7 @@ class Aggregator(nn.Module):
             for e in extra_sum:
                 z = z + e
             slope = 1.0   # the second LayerNorm has no activation in front: slope 1 = identity
-        y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p)
+        y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p, yn_out=self.norm_out)
         self.last_normalized = yn
         return y
 
@@ -249,14 +250,14 @@ class LiteralKG(nn.Module):
         return self._att
 
     # ------------------------------------------------------------------ a6/a7 encoder
-    def _gate(self, ent, num, txt):
+    def _gate(self, ent, num, txt, out=None):
         a = self.args
         if a.use_num_lit and a.use_txt_lit:
-            return self.emb_mul_lit(ent, num, txt)
+            return self.emb_mul_lit(ent, num, txt, out)
         if a.use_num_lit:
-            return self.emb_num_lit(ent, num)
+            return self.emb_num_lit(ent, num, out)
         if a.use_txt_lit:
-            return self.emb_txt_lit(ent, txt)
+            return self.emb_txt_lit(ent, txt, out)
         return ent
 
     def _literals(self):
@@ -273,12 +274,18 @@ class LiteralKG(nn.Module):
 
     def gat_embeddings(self):
         att = self._attention()
-        cur = self.gate_embeddings()
+        # every producer writes its column slice of the concatenated table directly (no torch.cat pass)
+        cb = ops.CatBuffer(self.n_entities, self.conv_dim_list, self.entity_embed.weight.device)
+        cur = self._gate(self.entity_embed.weight, *self._literals(), out=cb.slot(0))
         kept = [cur]
         for idx, layer in enumerate(self.aggregator_layers):
-            cur = layer(cur, att, kept, self.lamda, self.alpha, idx + 1)
+            layer.norm_out = cb.slot(idx + 1)
+            try:
+                cur = layer(cur, att, kept, self.lamda, self.alpha, idx + 1)
+            finally:
+                layer.norm_out = None
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused
-        cat = torch.cat(kept, dim=1)
+        cat = ops.assemble_cat(cb, kept)
         if self.scale_gat_dim is not None:
             return F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
         return cat

@@ -221,12 +221,14 @@ class _ActLayerNorm(Function):
     The dropout mask is counter-based (seed, element index) and regenerated in the backward."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed):
+    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed, yn_out):
         _need_gpu(z, gamma, beta)
         z = _f32_rows(z)
         n, d = z.shape
         y = torch.empty((n, d), dtype=torch.float32, device=z.device)
-        yn = torch.empty((n, d), dtype=torch.float32, device=z.device) if want_norm else None
+        yn = None
+        if want_norm:   # yn_out: a column slice of the concat buffer (CatBuffer), written in place
+            yn = yn_out if yn_out is not None else torch.empty((n, d), dtype=torch.float32, device=z.device)
         mean = torch.empty(n, dtype=torch.float32, device=z.device)
         rstd = torch.empty(n, dtype=torch.float32, device=z.device)
         N.call("lkg_act_layernorm_fwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta),
@@ -244,7 +246,7 @@ class _ActLayerNorm(Function):
         z, gamma, y, mean, rstd = ctx.saved_tensors
         slope, norm_eps, drop_p, seed = ctx.cfg
         n, d = z.shape
-        none = (None,) * 9
+        none = (None,) * 10
         if gy is None and gyn is None:
             return none
         gy = _f32_rows(gy) if gy is not None else None
@@ -265,20 +267,57 @@ def new_seed() -> int:
 
 
 def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS,
-                  drop_p: float = 0.0, seed: Optional[int] = None):
+                  drop_p: float = 0.0, seed: Optional[int] = None, yn_out: Optional[torch.Tensor] = None):
     if drop_p > 0 and seed is None:
         seed = new_seed()
-    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0)
+    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0, yn_out)
+
+
+# ----------------------------------------------------------------------------- concat without the copy
+class CatBuffer:
+    """The N x (sum of widths) table that torch.cat(all_embed, dim=1) would build (model.py:309/314), allocated up
+    front so that producers write their column slice directly (ld = total width) and no concat pass runs."""
+
+    def __init__(self, n: int, widths: Sequence[int], device):
+        self.widths = list(widths)
+        self.offsets = [0]
+        for w in self.widths:
+            self.offsets.append(self.offsets[-1] + w)
+        self.buf = torch.empty((n, self.offsets[-1]), dtype=torch.float32, device=device)
+
+    def slot(self, k: int) -> torch.Tensor:
+        return self.buf[:, self.offsets[k]:self.offsets[k + 1]]
+
+
+class _AssembleCat(Function):
+    @staticmethod
+    def forward(ctx, holder: CatBuffer, *parts):
+        for k, p in enumerate(parts):
+            s = holder.slot(k)
+            if p.data_ptr() != s.data_ptr() or p.stride() != s.stride():
+                s.copy_(p)                       # a part that was not produced in place (e.g. the raw entity table)
+        ctx.offsets = holder.offsets
+        return holder.buf
+
+    @staticmethod
+    def backward(ctx, g):
+        o = ctx.offsets
+        return (None, *[g[:, o[k]:o[k + 1]] for k in range(len(o) - 1)])
+
+
+def assemble_cat(holder: CatBuffer, parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _AssembleCat.apply(holder, *parts)
 
 
 # ----------------------------------------------------------------------------- K6 gate blend
 class _GateBlend(Function):
     @staticmethod
-    def forward(ctx, x, gpre, zpre):
+    def forward(ctx, x, gpre, zpre, out):
         _need_gpu(x, gpre, zpre)
         x, gpre, zpre = _f32_rows(x), _f32_rows(gpre), _f32_rows(zpre)
         n, d = x.shape
-        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((n, d), dtype=torch.float32, device=x.device)
         N.call("lkg_gate_blend_fwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
                N.ptr(out), _ld(out), _stream())
         ctx.save_for_backward(x, gpre, zpre)
@@ -292,11 +331,11 @@ class _GateBlend(Function):
         gx, gg, gz = (torch.empty((n, d), dtype=torch.float32, device=x.device) for _ in range(3))
         N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
                N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), _stream())
-        return gx, gg, gz
+        return gx, gg, gz, None
 
 
-def gate_blend(x, gpre, zpre):
-    return _GateBlend.apply(x, gpre, zpre)
+def gate_blend(x, gpre, zpre, out: Optional[torch.Tensor] = None):
+    return _GateBlend.apply(x, gpre, zpre, out)
 
 
 # ----------------------------------------------------------------------------- K8 TransE scoring
