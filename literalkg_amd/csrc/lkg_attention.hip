@@ -75,6 +75,11 @@ __global__ __launch_bounds__(TEAM == 1 ? 256 : 64 * TEAM) void edge_softmax_kern
 #pragma unroll
     for (int i = 0; i < CPL; ++i) live[i] = (sl + i * LPE) < nchunk;
 
+    // rows of at most 64 entries (nearly all of them) never leave the registers: lane i keeps the logit of
+    // entry i and the softmax statistics are two wave reductions; longer rows park their logits in val_out
+    const bool in_regs = TEAM == 1 && end - start <= 64;
+    float mylogit = -INFINITY;
+
     for (int base = start + 64 * wave_i; base < end; base += 64 * TEAM) {
         const int cnt = min(64, end - base);
         const int last = cnt - 1;
@@ -132,12 +137,26 @@ __global__ __launch_bounds__(TEAM == 1 ? 256 : 64 * TEAM) void edge_softmax_kern
             for (int u = 0; u < U; ++u) {
                 const float tot = group_sum<LPE>(part[u]);
                 const int idx = k + u * EPW + sub;
-                if (sl == 0 && idx < cnt) {
+                if (in_regs) {
+                    // entry e = k + u*EPW + s was summed by sub-group s: lane e fetches it from that group's lane 0
+                    const int rel_e = lane - (k + u * EPW);
+                    const float mine = __shfl(tot, (rel_e & (EPW - 1)) * LPE, 64);
+                    if (rel_e >= 0 && rel_e < EPW) mylogit = mine;
+                    if (logits_out && sl == 0 && idx < cnt) logits_out[base + idx] = tot;
+                } else if (sl == 0 && idx < cnt) {
                     val_out[base + idx] = tot;
                     if (logits_out) logits_out[base + idx] = tot;
                 }
             }
         }
+    }
+    if (in_regs) {
+        const bool has = lane < end - start;
+        const float m = wave_max(has ? mylogit : -INFINITY);
+        const float e = has ? expf(mylogit - m) : 0.f;
+        const float s = wave_sum(e);
+        if (has) val_out[start + lane] = e / s;
+        return;
     }
     // the logits were written by other lanes (TEAM > 1: other waves) of this workgroup: make them visible
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
