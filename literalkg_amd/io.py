@@ -48,5 +48,10 @@ def laplacian_values(g: KGStructure, kind: str = "random-walk") -> torch.Tensor:
 def initial_a_in(n_entities: int, h, t, r, kind: str = "random-walk") -> torch.Tensor:
     """The sparse COO N x N tensor DataLoader.A_in holds (dataloader.py:494-495): coalesced, int64 indices."""
     g = KGStructure.from_triples(n_entities, h, t, r, with_transpose=False)
-    return torch.sparse_coo_tensor(g.coo_indices(), laplacian_values(g, kind), (n_entities, n_entities),
-                                   is_coalesced=True)
+    idx, val = g.coo_indices(), laplacian_values(g, kind)
+    if kind == "symmetric":
+        # a tail without out-edges under relation r has d_r(t)^-1/2 = inf -> 0 (dataloader.py:467-468) and
+        # scipy's diagonal products do not store those entries: the reference's pattern omits them
+        keep = val != 0
+        idx, val = idx[:, keep], val[keep]
+    return torch.sparse_coo_tensor(idx, val, (n_entities, n_entities), is_coalesced=True)

@@ -220,9 +220,39 @@ def trajectory_case(ref_model, name, args, n, h, t, r, seed, n_steps, refresh_af
     save(name, **arrs)
 
 
+def loader_laplacian_case(name, n, h, t, r):
+    """The reference's OWN create_adjacency_dict / create_laplacian_dict (dataloader.py:449-495) run on a bare
+    DataLoader object holding just the attributes those two methods read (its __init__ needs pickles and
+    files that are not shipped)."""
+    import collections
+    sys.path.insert(0, REF)
+    import dataloader as ref_dl
+    out = dict(n=np.int64(n), h=h, t=t, r=r)
+    for kind in ("random-walk", "symmetric"):
+        dl = object.__new__(ref_dl.DataLoader)
+        dl.n_head_tail = n
+        dl.laplacian_type = kind
+        dl.train_relation_dict = collections.defaultdict(list)
+        for hh, tt, rr in zip(h.tolist(), t.tolist(), r.tolist()):
+            dl.train_relation_dict[rr].append((hh, tt))
+        with np.errstate(divide="ignore"):
+            dl.create_adjacency_dict()
+            dl.create_laplacian_dict()
+        a = dl.A_in.coalesce()
+        key = kind.replace("-", "_")
+        out[key + "_indices"] = a.indices().numpy()
+        out[key + "_values"] = a.values().numpy()
+    save(name, **out)
+
+
 def main():
     ref_model, ref_model_bce = ref_modules()
     rng = np.random.default_rng(2022)
+    if "--only-laplacian" in sys.argv:
+        rng = np.random.default_rng(4242)
+        lh, lt, lr = random_graph(rng, 260, 2600, 5, 10)       # (h,r,t) distinct, some (h,t) under two relations
+        loader_laplacian_case("laplacian_rand260", 260, lh, lt, lr)
+        return
     if "--only-trajectory" in sys.argv:
         rng = np.random.default_rng(777)
         th, tt_, tr = random_graph(rng, 200, 1400, 4, 6)

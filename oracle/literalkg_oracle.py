@@ -339,4 +339,5 @@ def laplacian_a_in(n_entities: int, h: torch.Tensor, t: torch.Tensor, r: torch.T
         m = torch.sparse_coo_tensor(torch.stack([hh, tt]), w, (n_entities, n_entities))
         acc = m if acc is None else acc + m
     acc = acc.coalesce()
-    return torch.sparse_coo_tensor(acc.indices(), acc.values().float(), acc.shape).coalesce()
+    keep = acc.values() != 0          # scipy's diagonal products do not store the inf -> 0 entries
+    return torch.sparse_coo_tensor(acc.indices()[:, keep], acc.values()[keep].float(), acc.shape).coalesce()

@@ -189,3 +189,20 @@ def test_ingest_the_reference_kg_file(native):
     rs = torch.zeros(n).index_add_(0, a.indices()[0], a.values())
     assert abs(float(rs[0]) - 9.0) < 1e-5                            # row 0 sums to 9
     assert a._nnz() == len(h) - 33                                   # its 33 duplicate (h,t) pairs are merged
+
+
+@pytest.mark.parametrize("kind", ["random-walk", "symmetric"])
+def test_initial_a_in_matches_the_reference_loader(native, kind):
+    """Fixture produced by the reference's own create_adjacency_dict / create_laplacian_dict
+    (dataloader.py:449-495, oracle/gen_golden.py --only-laplacian)."""
+    from literalkg_amd import io
+    from oracle import literalkg_oracle as O
+    gd = load_golden("laplacian_rand260")
+    n = int(gd["n"])
+    key = kind.replace("-", "_")
+    a = io.initial_a_in(n, gd["h"], gd["t"], gd["r"], kind)
+    assert np.array_equal(a.indices().numpy(), gd[key + "_indices"])
+    np.testing.assert_allclose(a.values().numpy(), gd[key + "_values"], rtol=1e-6, atol=1e-7)
+    want = O.laplacian_a_in(n, *(torch.from_numpy(gd[k]) for k in "htr"), kind)     # pins the oracle's restatement too
+    assert np.array_equal(want.indices().numpy(), gd[key + "_indices"])
+    np.testing.assert_allclose(want.values().numpy(), gd[key + "_values"], rtol=1e-6, atol=1e-7)
