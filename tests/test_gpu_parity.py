@@ -706,3 +706,27 @@ def test_gin_ignores_prune_flag(L, gpu_device):
     loss = m(*batch, device=gpu_device, mode="pre_training")
     assert m.gat_rows is None and m.gat_embed.shape[0] == int(gd["n"])
     np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- HIP path vs the plain-C oracle
+@pytest.mark.parametrize("d", [128, 256])
+def test_hip_matches_plain_c_oracle(L, ops, gpu_device, d):
+    """oracle/lkg_oracle.c: scalar C loops with double accumulation, independent of ATen."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(d)
+    n = 4000
+    h, t, r = rand_graph(rng, n, 50000, n_rel=8, long_rows=[(17, 700)])
+    extra = np.stack([h[:100], (r[:100] + 3) % 8, t[:100]], 1)
+    trip = np.unique(np.concatenate([np.stack([h, r, t], 1), extra]), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    ent = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    rel = (rng.standard_normal((8, d)) * 0.3).astype(np.float32)
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    val, _ = ops.edge_softmax(g, torch.from_numpy(ent).to(gpu_device), torch.from_numpy(rel).to(gpu_device))
+    rows, cols, want = c_oracle.attention(h, t, r, ent, rel)
+    assert np.array_equal(g.coo_indices().cpu().numpy(), np.stack([rows, cols]))
+    np.testing.assert_allclose(val.cpu().numpy(), want, rtol=1e-4, atol=1e-7)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    got = ops.spmm_raw(g.rowptr, g.col, val, torch.from_numpy(x).to(gpu_device), n, long_rows=g.long_rows(False))
+    ref = c_oracle.spmm(g.host("rowptr"), g.host("col"), val.cpu().numpy(), x)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)

@@ -121,3 +121,26 @@ def test_training_trajectory(name):
     np.testing.assert_allclose(a.values().numpy(), g["final_a_values"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(p["entity_embed.weight"].detach().numpy(), g["f/entity_embed.weight"], rtol=1e-4,
                                atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- plain-C restatement (oracle/lkg_oracle.c)
+@pytest.mark.parametrize("name", golden_names("attention_"))
+def test_c_oracle_attention(name):
+    from oracle import c_oracle
+    g = load_golden(name)
+    rows, cols, vals = c_oracle.attention(g["h"], g["t"], g["r"], g["entity"], g["relation"])
+    assert np.array_equal(np.stack([rows, cols]), g["a_indices"])            # bit-exact vs the reference's coalesce
+    np.testing.assert_allclose(vals, g["a_values"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["encoder_gcn_l1", "encoder_sage_l2"])
+def test_c_oracle_spmm(name):
+    from oracle import c_oracle
+    g = load_golden(name)
+    n = int(g["n"])
+    a = _a_in(g)
+    rowptr = np.zeros(n + 1, np.int64)
+    np.add.at(rowptr, g["a_indices"][0] + 1, 1)
+    x = g["p/entity_embed.weight"]
+    got = c_oracle.spmm(np.cumsum(rowptr), g["a_indices"][1], g["a_values"], x)
+    np.testing.assert_allclose(got, O.aggregate(a, torch.from_numpy(x)).numpy(), rtol=1e-5, atol=1e-6)
