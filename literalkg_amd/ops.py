@@ -112,6 +112,8 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
     long_rows = g.long_rows(False, row_lo, row_hi)
     val = out if out is not None else torch.empty(g.nnz, dtype=torch.float32, device=ent.device)
     logits = torch.empty(g.nnz, dtype=torch.float32, device=ent.device) if want_logits else None
+    if g.nnz == 0:          # no stored entry: nothing to refresh (the reference returns an empty A_in)
+        return val, logits
     N.call("lkg_edge_softmax_f32", row_hi - row_lo, row_lo, ent.shape[1], g.rowptr.data_ptr() + 4 * row_lo,
            N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
            N.ptr(logits), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,

@@ -730,3 +730,45 @@ def test_hip_matches_plain_c_oracle(L, ops, gpu_device, d):
     got = ops.spmm_raw(g.rowptr, g.col, val, torch.from_numpy(x).to(gpu_device), n, long_rows=g.long_rows(False))
     ref = c_oracle.spmm(g.host("rowptr"), g.host("col"), val.cpu().numpy(), x)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- edge cases the reference's loops tolerate
+def test_edge_cases_small_batches_dtypes_and_empty_graphs(L, ops, O, gpu_device):
+    gd = load_golden("encoder_gcn_l1")
+    m = _build_model(L, gd, gpu_device, "transr")
+    p = golden_params(gd)
+    cfg = golden_cfg(gd)
+    n = int(gd["n"])
+    a = torch.sparse_coo_tensor(torch.from_numpy(gd["a_indices"]), torch.from_numpy(gd["a_values"]), (n, n)).coalesce()
+    # a single triple, ids given as int32 (the module widens them)
+    one = [torch.tensor([x], dtype=torch.int32, device=gpu_device) for x in (3, 1, 5, 7)]
+    got = m(*one, device=gpu_device, mode="pre_training")
+    want = O.pre_training_loss(p, cfg, a, *[torch.tensor([x]) for x in (3, 1, 5, 7)])
+    np.testing.assert_allclose(float(got.detach()), float(want), rtol=1e-5)
+    got.backward()
+    # all triples identical: duplicate rows scatter-add into the same gradient rows
+    same = [torch.full((64,), x, dtype=torch.int64, device=gpu_device) for x in (3, 1, 5, 7)]
+    m.zero_grad()
+    l2 = m(*same, device=gpu_device, mode="pre_training")
+    l2.backward()
+    pc = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}
+    w2 = O.pre_training_loss(pc, cfg, a, *[torch.full((64,), x) for x in (3, 1, 5, 7)])
+    w2.backward()
+    np.testing.assert_allclose(float(l2.detach()), float(w2), rtol=1e-5)
+    torch.testing.assert_close(m.gat_trans_M.grad.cpu(), pc["gat_trans_M"].grad, rtol=1e-3, atol=1e-7)
+    torch.testing.assert_close(m.entity_embed.weight.grad.cpu(), pc["entity_embed.weight"].grad, rtol=1e-3, atol=1e-7)
+    # update_att on an edge list that leaves most rows (or all rows) empty
+    e = torch.zeros(0, dtype=torch.int64, device=gpu_device)
+    m(e, e, e, [0, 1], device=gpu_device, mode="update_att")
+    assert m.A_in._nnz() == 0
+    z = m(*same, device=gpu_device, mode="pre_training")           # side = 0 everywhere: still a finite loss
+    assert torch.isfinite(z)
+    hh = torch.tensor([n - 1], device=gpu_device)
+    m(hh, torch.tensor([0], device=gpu_device), torch.tensor([2], device=gpu_device), [2], device=gpu_device,
+      mode="update_att")
+    av = m.A_in.data
+    assert av._nnz() == 1 and float(av.values()[0]) == 1.0 and av.indices().flatten().tolist() == [n - 1, 0]
+    with pytest.raises(ValueError, match="empty graph"):
+        from literalkg_amd.sampler import KGBatchSampler
+        KGBatchSampler(L.KGStructure.from_triples(4, np.zeros(0, np.int64), np.zeros(0, np.int64), None,
+                                                  device=gpu_device), 3)
