@@ -117,12 +117,28 @@ def whole_path_timings(h, t, r, n, d, dev):
     step = timed(fwd_bwd)
     model.prune_to_batch = True          # exact: layers evaluated on the batch's L-hop frontier only
     pruned = timed(fwd_bwd)
+    model.prune_to_batch = False
+    # (ii) one aggregation layer forward (a1 + a2): SpMM(+self), Linear on the f32 MFMA GEMM, LeakyReLU/LayerNorm/
+    # dropout/normalise epilogue; and the dense GEMM of that layer alone against the f32 MFMA peak
+    from literalkg_amd import ops
+    att = model._attention()
+    ego = model.entity_embed.weight.detach()
+    layer = model.aggregator_layers[0]
+    with torch.no_grad():
+        layer_ms = timed(lambda: layer(ego, att, [ego], model.lamda, model.alpha, 1))
+        w, b = layer.linear.weight.detach(), layer.linear.bias.detach()
+        gemm_ms = timed(lambda: ops.gemm(ego, w, trans_b=True, bias=b))
+    gemm_tf = 2.0 * n * d * d / gemm_ms / 1e9
     e = len(h)
     return {"config": f"LiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, same graph",
             "update_att_ms": upd, "update_att_edges_per_s": e / upd * 1e3,
             "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
             "pre_training_step_edges_per_s": e / step * 1e3,
-            "pre_training_forward_backward_ms_prune_to_batch": pruned}
+            "pre_training_forward_backward_ms_prune_to_batch": pruned,
+            "layer_forward_ms": layer_ms, "layer_forward_edges_per_s": e / layer_ms * 1e3,
+            "roofline_gemm": {"bound": "mfma", "kernel": f"gemm_kernel<NT> Linear forward {n}x{d}x{d} (f32 MFMA 32x32x2)",
+                              "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
+                              "avg_launch_ms": gemm_ms}}
 
 
 def main():
