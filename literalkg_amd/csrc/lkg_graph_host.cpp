@@ -111,9 +111,7 @@ extern "C" int lkg_csr_build(int64_t n_entities, int64_t n_edges, const int64_t 
         }
     }
     rowptr[n_entities] = (int32_t)nnz;
-    if (n_edges > 0 || eptr) {
-        if (eptr) eptr[nnz] = (int32_t)n_edges;
-    }
+    if (eptr) eptr[nnz] = (int32_t)n_edges;
     *nnz_out = nnz;
     return LKG_OK;
 }
