@@ -340,8 +340,13 @@ class LiteralKG(nn.Module):
 
     # ------------------------------------------------------------------ a4/a5 attention refresh
     def _structure_for(self, h_list, t_list, r_list, relations) -> KGStructure:
-        key = (h_list.data_ptr(), t_list.data_ptr(), r_list.data_ptr(), h_list.numel(), h_list._version,
-               t_list._version, r_list._version, tuple(relations) if relations is not None else None,
+        # content fingerprint, not identity: a driver re-uploads the lists every epoch (main_pretraining.py:135-137)
+        # and the allocator may hand the same address to a different list
+        hl, tl, rl = h_list.long(), t_list.long(), r_list.long()
+        mix = hl * 1000003 + tl * 998244353 + rl * 1315423911
+        sums = torch.stack([hl.sum(), tl.sum(), rl.sum(), mix.sum(), (mix ^ (mix >> 17)).sum()]).tolist() \
+            if hl.numel() else [0]
+        key = (h_list.numel(), tuple(sums), tuple(relations) if relations is not None else None,
                str(self.A_in.device))
         if self._triple_graph is not None and self._triple_key == key:
             return self._triple_graph

@@ -772,3 +772,26 @@ def test_edge_cases_small_batches_dtypes_and_empty_graphs(L, ops, O, gpu_device)
         from literalkg_amd.sampler import KGBatchSampler
         KGBatchSampler(L.KGStructure.from_triples(4, np.zeros(0, np.int64), np.zeros(0, np.int64), None,
                                                   device=gpu_device), 3)
+
+
+def test_update_att_structure_cache_follows_content(L, O, gpu_device):
+    """The (h,t)-sorted structure is cached across epochs by CONTENT of the edge lists: a re-uploaded copy reuses
+    it, a different list of the same length (possibly at the same address) does not."""
+    gd = load_golden("encoder_gcn_l1")
+    m = _build_model(L, gd, gpu_device, "transr")
+    n, n_rel = int(gd["n"]), int(gd["n_rel"])
+    rel = list(range(n_rel))
+    h, t, r = (torch.from_numpy(gd[k]).to(gpu_device) for k in "htr")
+    m(h, t, r, rel, device=gpu_device, mode="update_att")
+    g1 = m._triple_graph
+    m(h.clone(), t.clone(), r.clone(), rel, device=gpu_device, mode="update_att")
+    assert m._triple_graph is g1                                   # same content, new tensors: reused
+    t2 = t.clone()
+    t2[:50] = (t2[:50] + 1) % n
+    t.copy_(t2)                                                    # same tensor object and address, new content
+    m(h, t, r, rel, device=gpu_device, mode="update_att")
+    assert m._triple_graph is not g1
+    p = golden_params(gd)
+    want = O.attention_refresh(n, p["entity_embed.weight"], p["relation_embed.weight"], h.cpu(), t.cpu(), r.cpu()).coalesce()
+    assert torch.equal(m.A_in.data.indices().cpu(), want.indices())
+    torch.testing.assert_close(m.A_in.data.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
