@@ -67,10 +67,13 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // tanh on the hot elementwise paths (attention logits: 4 per lane per edge; gate blend).  The ocml tanhf costs
 // ~40 VALU instructions; this form is ~15: an odd series below 0.25 (truncation < 2e-9 relative) and
 // 1 - 2 / (exp(2|x|) + 1) above, on v_exp_f32 / v_rcp_f32.  Absolute error <= 2e-7 over the real line.
+__device__ __forceinline__ float tanh_series(float x) {   // |x| < 0.25 only
+    const float x2 = x * x;
+    return x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+}
 __device__ __forceinline__ float tanh_fast(float x) {
     const float ax = fminf(fabsf(x), 10.f);
-    const float x2 = x * x;
-    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float poly = tanh_series(x);
     const float e = __expf(2.f * ax);
     const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
     return ax < 0.25f ? poly : big;
