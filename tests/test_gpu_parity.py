@@ -795,3 +795,16 @@ def test_update_att_structure_cache_follows_content(L, O, gpu_device):
     want = O.attention_refresh(n, p["entity_embed.weight"], p["relation_embed.weight"], h.cpu(), t.cpu(), r.cpu()).coalesce()
     assert torch.equal(m.A_in.data.indices().cpu(), want.indices())
     torch.testing.assert_close(m.A_in.data.values().cpu(), want.values(), rtol=1e-5, atol=1e-7)
+
+
+def test_runs_under_autograd_anomaly_mode(L, gpu_device):
+    """The reference's driver keeps torch.autograd.set_detect_anomaly(True) on (main_pretraining.py:45)."""
+    gd = load_golden("encoder_gcn_l2_gatenum")
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.train()
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    with torch.autograd.detect_anomaly(check_nan=True):
+        loss = m(*batch, device=gpu_device, mode="pre_training")
+        loss.backward()
+    np.testing.assert_allclose(loss.item(), float(gd["loss"]), rtol=1e-5)
+    assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)
