@@ -125,14 +125,20 @@ int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowpt
  * then softmax of v over the stored entries of each head row.
  * Replaces update_attention_batch + coalesce + torch.sparse.softmax(A.cpu(), dim=1)
  * (model.py:430-471).  eptr may be NULL when no (h,t) pair is duplicated
- * (then rel is indexed by entry).  logits_out (nullable) receives the merged
+ * (then rel is indexed by entry, and rel_first / dup_* / nnz are ignored).  With eptr: rel_first
+ * int32[nnz] holds rel[eptr[j]] per entry; dup_entries int32[n_dup] lists the entries covering more than
+ * one raw edge and dup_rows their head rows (relative to row_offset); a pre-pass adds their further
+ * relations' terms so that the main kernel's hot loop never chases eptr -> rel; nnz = entries in val_out
+ * (the rows' entry range must start at 0, i.e. val_out is cleared from its first element).  logits_out (nullable) receives the merged
  * pre-softmax logits, val_out the attention values, both float[nnz].
  * row_offset: rowptr holds n_rows+1 offsets for head rows row_offset..row_offset+n_rows
  * (a row-range shard of a larger graph; ent always holds the full table).
  * long_rows / n_long / long_thresh: as for lkg_spmm_csr_f32 (one workgroup per long row).  */
 int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
                          const int32_t *col, const int32_t *eptr, const int32_t *rel,
-                         const float *ent, int64_t ld_ent, const float *relemb, int64_t ld_rel,
+                         const int32_t *rel_first, const int32_t *dup_entries,
+                         const int32_t *dup_rows, int32_t n_dup, int64_t nnz, const float *ent,
+                         int64_t ld_ent, const float *relemb, int64_t ld_rel,
                          float *val_out, float *logits_out, const int32_t *long_rows, int32_t n_long,
                          int32_t long_thresh, void *stream);
 

@@ -38,6 +38,34 @@ struct dot_ops<float> {
     static __device__ __forceinline__ float zero() { return 0.f; }
 };
 
+// Pre-pass for the (rare) stored entries whose (h,t) pair occurs under several relations: one wave per such entry
+// writes the logit terms of its 2nd, 3rd ... raw edge to val_out[entry]; the main kernel adds the first edge's
+// term on top.  Keeping this out of the main kernel keeps the hot loop at the no-duplicate register count.
+template <typename V>
+__global__ __launch_bounds__(256) void extra_relations_kernel(int n_dup, long row_offset, int nchunk,
+                                                               const int *__restrict__ dup_entries,
+                                                               const int *__restrict__ dup_rows,
+                                                               const int *__restrict__ col,
+                                                               const int *__restrict__ eptr,
+                                                               const int *__restrict__ rel,
+                                                               const float *__restrict__ ent, long ld_ent,
+                                                               const float *__restrict__ relemb, long ld_rel,
+                                                               float *__restrict__ val_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_dup) return;
+    const int j = dup_entries[i];
+    const V *hs = reinterpret_cast<const V *>(ent + (row_offset + dup_rows[i]) * ld_ent);
+    const V *ts = reinterpret_cast<const V *>(ent + (long)col[j] * ld_ent);
+    float extra = 0.f;
+    for (int e = eptr[j] + 1; e < eptr[j + 1]; ++e) {
+        const V *rs = reinterpret_cast<const V *>(relemb + (long)rel[e] * ld_rel);
+        for (int ch = lane; ch < nchunk; ch += 64) extra += dot_ops<V>::tanh_dot(ts[ch], hs[ch], rs[ch]);
+    }
+    extra = wave_sum(extra);
+    if (lane == 0) val_out[j] = extra;
+}
+
 // One launch, two kinds of workgroup (256 threads = 4 waves), as in lkg_spmm.hip:
 //   blocks [0, n_long)   : one LONG head row (> long_thresh entries) per workgroup; the four waves take interleaved
 //                          64-entry chunks and meet in LDS for the softmax statistics;
@@ -45,9 +73,10 @@ struct dot_ops<float> {
 template <typename V, int LPE, int CPL, int U, bool DUPS>
 __global__ __launch_bounds__(256) void edge_softmax_kernel(
     int n_rows, long row_offset, int nchunk, const int *__restrict__ rowptr, const int *__restrict__ col,
-    const int *__restrict__ eptr, const int *__restrict__ rel, const float *__restrict__ ent, long ld_ent,
-    const float *__restrict__ relemb, long ld_rel, float *__restrict__ val_out, float *__restrict__ logits_out,
-    const int *__restrict__ long_rows, int n_long, int long_thresh) {
+    const int *__restrict__ eptr, const int *__restrict__ rel, const int *__restrict__ rel_first,
+    const float *__restrict__ ent, long ld_ent, const float *__restrict__ relemb, long ld_rel,
+    float *__restrict__ val_out, float *__restrict__ logits_out, const int *__restrict__ long_rows, int n_long,
+    int long_thresh) {
     using ops = dot_ops<V>;
     constexpr int EPW = 64 / LPE;
     __shared__ float red[4];
@@ -91,12 +120,10 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
         const int last = cnt - 1;
         const int jl = base + min(lane, last);
         const int c = col[jl];
-        int e0 = jl, e1 = jl + 1;
-        if constexpr (DUPS) {
-            e0 = eptr[jl];
-            e1 = eptr[jl + 1];
-        }
-        const int r0 = rel[e0];
+        // relation of the entry's FIRST raw edge: entry-indexed (rel_first) so that it does not wait for eptr
+        const int r0 = DUPS ? rel_first[jl] : rel[jl];
+        // terms of the entry's further raw edges, left in val_out by extra_relations_kernel (0 for most entries)
+        const float pre = DUPS ? val_out[jl] : 0.f;
         for (int k = 0; k < cnt; k += EPW * U) {
             float part[U];
             int cc[U], rr[U];
@@ -125,24 +152,11 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
                 for (int i = 0; i < CPL; ++i) p += live[i] ? ops::tanh_dot(tv[u][i], hv[i], rv[u][i]) : 0.f;
                 part[u] = p;
             }
-            if constexpr (DUPS) {
-                // rare: further raw edges of the same (h,t) entry, other relations
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idc = min(k + u * EPW + sub, last);
-                    const int f0 = __shfl(e0, idc, 64), f1 = __shfl(e1, idc, 64);
-                    for (int e = f0 + 1; e < f1; ++e) {
-                        const V *rs = reinterpret_cast<const V *>(relemb + (long)rel[e] * ld_rel);
-#pragma unroll
-                        for (int i = 0; i < CPL; ++i)
-                            part[u] += live[i] ? ops::tanh_dot(tv[u][i], hv[i], rs[min(sl + i * LPE, nchunk - 1)]) : 0.f;
-                    }
-                }
-            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float tot = group_sum<LPE>(part[u]);
                 const int idx = k + u * EPW + sub;
+                float tot = group_sum<LPE>(part[u]);
+                if constexpr (DUPS) tot += __shfl(pre, min(idx, last), 64);
                 if (in_regs) {
                     // entry e = k + u*EPW + s was summed by sub-group s: lane e fetches it from that group's lane 0
                     const int rel_e = lane - (k + u * EPW);
@@ -195,7 +209,9 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 struct EsArgs {
     int64_t n_rows, row_offset;
     int nchunk;
-    const int *rowptr, *col, *eptr, *rel;
+    const int *rowptr, *col, *eptr, *rel, *rel_first, *dup_entries, *dup_rows;
+    int n_dup;
+    int64_t nnz;
     const float *ent;
     int64_t ld_ent;
     const float *relemb;
@@ -207,9 +223,19 @@ struct EsArgs {
 
 template <typename V, int LPE, int CPL, int U, bool DUPS>
 int launch2(const EsArgs &a, hipStream_t s) {
+    if constexpr (DUPS) {
+        if (hipMemsetAsync(a.val_out, 0, sizeof(float) * a.nnz, s) != hipSuccess) {
+            lkg_set_error("lkg_edge_softmax_f32: hipMemsetAsync failed");
+            return LKG_ERR_HIP;
+        }
+        if (a.n_dup > 0)
+            hipLaunchKernelGGL((extra_relations_kernel<V>), dim3((unsigned)((a.n_dup + 3) / 4)), dim3(256), 0, s,
+                               a.n_dup, (long)a.row_offset, a.nchunk, a.dup_entries, a.dup_rows, a.col, a.eptr, a.rel,
+                               a.ent, (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out);
+    }
     const int64_t blocks = (a.n_rows + 3) / 4 + a.n_long;
     hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, DUPS>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col, a.eptr, a.rel, a.ent,
+                       (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col, a.eptr, a.rel, a.rel_first, a.ent,
                        (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out, a.logits_out, a.long_rows, a.n_long,
                        a.long_thresh);
     LKG_CHECK_LAUNCH("lkg_edge_softmax_f32");
@@ -224,10 +250,12 @@ int launch(const EsArgs &a, hipStream_t s) {
 template <typename V>
 int dispatch(const EsArgs &a, hipStream_t s) {
     const int nchunk = a.nchunk;
-    if (nchunk <= 8) return launch<V, 8, 1, 4>(a, s);
-    if (nchunk <= 16) return launch<V, 16, 1, 4>(a, s);
-    if (nchunk <= 32) return launch<V, 32, 1, 4>(a, s);
-    if (nchunk <= 64) return launch<V, 64, 1, 4>(a, s);
+    // U = 2 entries in flight per sub-group: measured best on one box (D=256 zipf: U=1 2.65 ms, U=2 2.29, U=4 2.63 --
+    // at U=4 the 91 VGPRs of the tanh temporaries cut the occupancy to 5 waves per SIMD)
+    if (nchunk <= 8) return launch<V, 8, 1, 2>(a, s);
+    if (nchunk <= 16) return launch<V, 16, 1, 2>(a, s);
+    if (nchunk <= 32) return launch<V, 32, 1, 2>(a, s);
+    if (nchunk <= 64) return launch<V, 64, 1, 2>(a, s);
     if (nchunk <= 128) return launch<V, 64, 2, 2>(a, s);
     if (nchunk <= 192) return launch<V, 64, 3, 2>(a, s);
     if (nchunk <= 256) return launch<V, 64, 4, 1>(a, s);
@@ -238,18 +266,22 @@ int dispatch(const EsArgs &a, hipStream_t s) {
 }  // namespace
 
 extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
-                                    const int32_t *col, const int32_t *eptr, const int32_t *rel, const float *ent,
-                                    int64_t ld_ent, const float *relemb, int64_t ld_rel, float *val_out,
-                                    float *logits_out, const int32_t *long_rows, int32_t n_long,
-                                    int32_t long_thresh, void *stream) {
+                                    const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                                    const int32_t *rel_first, const int32_t *dup_entries, const int32_t *dup_rows,
+                                    int32_t n_dup, int64_t nnz, const float *ent, int64_t ld_ent,
+                                    const float *relemb, int64_t ld_rel, float *val_out, float *logits_out,
+                                    const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_offset >= 0, "lkg_edge_softmax_f32: bad row range");
     LKG_REQUIRE(d > 0 && ld_ent >= d && ld_rel >= d, "lkg_edge_softmax_f32: bad d/strides (d=%d)", d);
     LKG_REQUIRE(n_long >= 0 && (n_long == 0 || (long_rows && long_thresh >= 64)),
                 "lkg_edge_softmax_f32: long-row list needs a pointer and a threshold >= 64");
     if (n_rows == 0) return LKG_OK;
     LKG_REQUIRE(rowptr && col && rel && ent && relemb && val_out, "lkg_edge_softmax_f32: null pointer");
+    LKG_REQUIRE(!eptr || (rel_first && nnz > 0 && n_dup >= 0 && (n_dup == 0 || (dup_entries && dup_rows))),
+                "lkg_edge_softmax_f32: eptr needs rel_first, nnz and the duplicate-entry list");
     const bool vec = (d % 4 == 0) && (ld_ent % 4 == 0) && (ld_rel % 4 == 0) && lkg_aligned16(ent) && lkg_aligned16(relemb);
-    EsArgs a{n_rows, row_offset, vec ? d / 4 : d, rowptr, col, eptr, rel, ent, ld_ent, relemb, ld_rel,
+    EsArgs a{n_rows, row_offset, vec ? d / 4 : d, rowptr, col, eptr, rel, rel_first, dup_entries, dup_rows, n_dup,
+             nnz, ent, ld_ent, relemb, ld_rel,
              val_out, logits_out, long_rows, n_long, long_thresh};
     hipStream_t s = (hipStream_t)stream;
     return vec ? dispatch<float4>(a, s) : dispatch<float>(a, s);

@@ -9,6 +9,7 @@ Layout (E_raw raw triples, nnz <= E_raw stored entries, N entities):
     col     int32[nnz]   tail of each entry, ascending inside a row  (== coalesced COO order)
     eptr    int32[nnz+1] entry j covers sorted raw edges eptr[j]..eptr[j+1]   (None when nnz == E_raw)
     rel     int32[E_raw] relation of each sorted raw edge
+    rel_first int32[nnz] relation of the first raw edge of each entry (only with eptr)
     t_rowptr/t_col/t_perm  the CSC: for tail t the heads pointing at it, and the CSR entry id of each
 """
 from __future__ import annotations
@@ -29,7 +30,7 @@ class KGStructure:
         self.n = 0
         self.nnz = 0
         self.n_raw = 0
-        self.rowptr = self.col = self.eptr = self.rel = None
+        self.rowptr = self.col = self.eptr = self.rel = self.rel_first = self.dup_entries = self.dup_rows = None
         self.t_rowptr = self.t_col = self.t_perm = None
         self.order = None           # int64 host: sorted raw edge k is input edge order[k]
         self.device = torch.device("cpu")
@@ -62,8 +63,14 @@ class KGStructure:
         g = cls()
         g.n, g.nnz, g.n_raw = n, int(nnz[0]), e
         g.order = order[:e]
-        g._host = dict(rowptr=rowptr, col=col[:g.nnz], rel=rel[:e],
-                       eptr=(eptr[:g.nnz + 1] if g.nnz != e else None))
+        dups = g.nnz != e
+        g._host = dict(rowptr=rowptr, col=col[:g.nnz], rel=rel[:e], eptr=None, rel_first=None, dup_entries=None,
+                       dup_rows=None)
+        if dups:   # stored entries covering several raw edges (the same (h,t) under several relations)
+            ep = eptr[:g.nnz + 1]
+            de = np.flatnonzero(np.diff(ep) > 1).astype(np.int32)
+            g._host.update(eptr=ep, rel_first=rel[:e][ep[:-1]], dup_entries=de,
+                           dup_rows=(np.searchsorted(rowptr, de, side="right") - 1).astype(np.int32))
         if with_transpose:
             t_rowptr = np.empty(n + 1, np.int32)
             t_col = np.empty(max(g.nnz, 1), np.int32)

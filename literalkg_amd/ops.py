@@ -114,8 +114,15 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
     logits = torch.empty(g.nnz, dtype=torch.float32, device=ent.device) if want_logits else None
     if g.nnz == 0:          # no stored entry: nothing to refresh (the reference returns an empty A_in)
         return val, logits
+    dup = (None, None, 0)
+    if g.has_dups:          # entries with several raw edges inside this row range (rows relative to row_lo)
+        de, dr = g.dup_entries, g.dup_rows
+        if row_lo != 0 or row_hi != g.n:
+            keep = (dr >= row_lo) & (dr < row_hi)
+            de, dr = de[keep].contiguous(), (dr[keep] - row_lo).contiguous()
+        dup = (N.ptr(de), N.ptr(dr), de.numel())
     N.call("lkg_edge_softmax_f32", row_hi - row_lo, row_lo, ent.shape[1], g.rowptr.data_ptr() + 4 * row_lo,
-           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
+           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, g.nnz, N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
            N.ptr(logits), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
            _stream())
     return val, logits
