@@ -219,6 +219,19 @@ int lkg_dot_score_bwd_f32(int64_t batch, int32_t dim, const float *emb, int64_t 
                           const int64_t *pos_t, const int64_t *neg_t, const float *pos, const float *neg,
                           float lambda, const float *g_loss, float *g_emb, int64_t ld_gemb, void *stream);
 
+/* f1  MLP head (model.py:499-519; model_bce.py:255-260, 423-436): y = BatchNorm1d(relu(z)) fused.
+ * training != 0: batch statistics (needs n > 1), running_mean / running_var updated with `momentum` (unbiased
+ * variance), like nn.BatchNorm1d; training == 0: the running buffers normalise.  save_mean / save_invstd
+ * float[d] feed the backward, which writes g_z and OVERWRITES g_gamma / g_beta.                          */
+int lkg_relu_batchnorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, const float *gamma,
+                               const float *beta, float eps, int32_t training, float momentum,
+                               float *running_mean, float *running_var, float *y, int64_t ldy,
+                               float *save_mean, float *save_invstd, void *stream);
+int lkg_relu_batchnorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, const float *gamma,
+                               const float *save_mean, const float *save_invstd, int32_t training,
+                               const float *g_y, int64_t ldgy, float *g_z, int64_t ldgz, float *g_gamma,
+                               float *g_beta, void *stream);
+
 /* Scores on already-projected rows (TransR form, model.py:413-426): same outputs
  * as lkg_transe_score_fwd_f32 but ph/pp/pn are dense batch x dim matrices.       */
 int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,

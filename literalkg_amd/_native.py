@@ -42,6 +42,8 @@ PROTOTYPES = {
                                   vp, f32, u64, vp],
     "lkg_dot_score_fwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_dot_score_bwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp],
+    "lkg_relu_batchnorm_fwd_f32": [i64, i32, vp, i64, vp, vp, f32, i32, f32, vp, vp, vp, i64, vp, vp, vp],
+    "lkg_relu_batchnorm_bwd_f32": [i64, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp],
     "lkg_gate_blend_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gate_blend_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp],

@@ -523,3 +523,127 @@ extern "C" int lkg_adam_step_f32(int64_t n, float *param, const float *grad, flo
     LKG_CHECK_LAUNCH("lkg_adam_step_f32");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// f1  MLP head (model.py:499-519, model_bce.py:255-260, 423-436):  y = BatchNorm1d(relu(z)) fused.
+// A workgroup owns 64 columns; its four waves stride over the rows (coalesced 256-B row segments) and meet in
+// LDS for the column statistics.  Training mode uses batch statistics (biased variance for the output, unbiased
+// for the running estimate, like nn.BatchNorm1d) and updates the running buffers; eval mode uses the buffers.
+namespace {
+__device__ __forceinline__ float col_reduce4(float v, float (*sm)[64], int g, int c) {
+    sm[g][c] = v;
+    __syncthreads();
+    const float r = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void relu_bn_fwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps, int training,
+                                                           float momentum, float *__restrict__ running_mean,
+                                                           float *__restrict__ running_var, float *__restrict__ y,
+                                                           long ldy, float *__restrict__ save_mean,
+                                                           float *__restrict__ save_invstd) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, lc = threadIdx.x & 63;
+    const bool ok = c < d;
+    float mean, invstd;
+    if (training) {
+        float s = 0.f;
+        for (long r = g; r < n; r += 4) s += ok ? fmaxf(z[r * ldz + c], 0.f) : 0.f;
+        mean = col_reduce4(s, sm, g, lc) / (float)n;
+        float q = 0.f;
+        for (long r = g; r < n; r += 4) {
+            const float a = ok ? fmaxf(z[r * ldz + c], 0.f) - mean : 0.f;
+            q = fmaf(a, a, q);
+        }
+        const float var = col_reduce4(q, sm, g, lc) / (float)n;
+        invstd = 1.f / sqrtf(var + eps);
+        if (ok && g == 0) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)n / (float)max(n - 1, 1L));
+        }
+    } else {
+        mean = ok ? running_mean[c] : 0.f;
+        invstd = ok ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
+    }
+    if (ok && g == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+    }
+    const float ga = ok ? gamma[c] : 0.f, be = ok ? beta[c] : 0.f;
+    for (long r = g; r < n; r += 4)
+        if (ok) y[r * ldy + c] = (fmaxf(z[r * ldz + c], 0.f) - mean) * invstd * ga + be;
+}
+
+__global__ __launch_bounds__(256) void relu_bn_bwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ save_mean,
+                                                           const float *__restrict__ save_invstd, int training,
+                                                           const float *__restrict__ g_y, long ldgy,
+                                                           float *__restrict__ g_z, long ldgz,
+                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, lc = threadIdx.x & 63;
+    const bool ok = c < d;
+    const float mean = ok ? save_mean[c] : 0.f, invstd = ok ? save_invstd[c] : 0.f, ga = ok ? gamma[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (long r = g; r < n; r += 4) {
+        const float dy = ok ? g_y[r * ldgy + c] : 0.f;
+        const float xh = ok ? (fmaxf(z[r * ldz + c], 0.f) - mean) * invstd : 0.f;
+        s1 += dy;
+        s2 = fmaf(dy, xh, s2);
+    }
+    s1 = col_reduce4(s1, sm, g, lc);
+    s2 = col_reduce4(s2, sm, g, lc);
+    if (ok && g == 0) {
+        g_beta[c] = s1;
+        g_gamma[c] = s2;
+    }
+    const float inv_n = 1.f / (float)n;
+    for (long r = g; r < n; r += 4) {
+        if (!ok) continue;
+        const float zz = z[r * ldz + c];
+        const float dy = g_y[r * ldgy + c];
+        float da;
+        if (training) {
+            const float xh = (fmaxf(zz, 0.f) - mean) * invstd;
+            da = ga * invstd * (dy - s1 * inv_n - xh * s2 * inv_n);
+        } else {
+            da = ga * invstd * dy;
+        }
+        g_z[r * ldgz + c] = zz > 0.f ? da : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int lkg_relu_batchnorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, const float *gamma,
+                                          const float *beta, float eps, int32_t training, float momentum,
+                                          float *running_mean, float *running_var, float *y, int64_t ldy,
+                                          float *save_mean, float *save_invstd, void *stream) {
+    LKG_REQUIRE(n > 0 && d > 0 && ldz >= d && ldy >= d, "lkg_relu_batchnorm_fwd_f32: bad sizes (n=%lld, d=%d)",
+                (long long)n, d);
+    LKG_REQUIRE(!training || n > 1, "lkg_relu_batchnorm_fwd_f32: training mode needs more than one row per batch");
+    LKG_REQUIRE(z && gamma && beta && running_mean && running_var && y && save_mean && save_invstd,
+                "lkg_relu_batchnorm_fwd_f32: null pointer");
+    hipLaunchKernelGGL(relu_bn_fwd_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (long)n,
+                       d, z, (long)ldz, gamma, beta, eps, training, momentum, running_mean, running_var, y, (long)ldy,
+                       save_mean, save_invstd);
+    LKG_CHECK_LAUNCH("lkg_relu_batchnorm_fwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_relu_batchnorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, const float *gamma,
+                                          const float *save_mean, const float *save_invstd, int32_t training,
+                                          const float *g_y, int64_t ldgy, float *g_z, int64_t ldgz, float *g_gamma,
+                                          float *g_beta, void *stream) {
+    LKG_REQUIRE(n > 0 && d > 0 && ldz >= d && ldgy >= d && ldgz >= d, "lkg_relu_batchnorm_bwd_f32: bad sizes");
+    LKG_REQUIRE(z && gamma && save_mean && save_invstd && g_y && g_z && g_gamma && g_beta,
+                "lkg_relu_batchnorm_bwd_f32: null pointer");
+    hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (long)n,
+                       d, z, (long)ldz, gamma, save_mean, save_invstd, training, g_y, (long)ldgy, g_z, (long)ldgz,
+                       g_gamma, g_beta);
+    LKG_CHECK_LAUNCH("lkg_relu_batchnorm_bwd_f32");
+    return LKG_OK;
+}

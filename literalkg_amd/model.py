@@ -218,6 +218,9 @@ class LiteralKG(nn.Module):
             Aggregator(self.conv_dim_list[k], self.conv_dim_list[k + 1], self.mess_dropout[k], self.aggregation_type,
                        self.use_residual, args) for k in range(self.n_layers))
 
+        if scoring == "transe" and self.scale_gat_dim is not None:
+            self.initialize_MLP()     # model_bce.py builds the MLP head in its constructor (255-260)
+
         # sparse, non-trainable, rides in state_dict like the reference's (model.py:257-261)
         empty = torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0), (n_entities, n_entities))
         self.A_in = nn.Parameter(empty, requires_grad=False)
@@ -381,6 +384,31 @@ class LiteralKG(nn.Module):
         lo, hi = s.min(), s.max()
         return ((s - lo) / (hi - lo) > self.milestone_score).int()
 
+    def initialize_MLP(self):
+        """The pair-classification head of model.py:499-504 (same module names, so checkpoints interchange)."""
+        self.fc1 = nn.Linear(self.scale_gat_dim * 2, 128)
+        self.norm1 = nn.BatchNorm1d(128)
+        self.fc2 = nn.Linear(128, 64)
+        self.norm2 = nn.BatchNorm1d(64)
+        self.fc3 = nn.Linear(64, 1)
+        dev = self.entity_embed.weight.device
+        for mod in (self.fc1, self.norm1, self.fc2, self.norm2, self.fc3):
+            mod.to(dev)
+
+    def train_MLP(self, head_ids, tail_ids):
+        """mode='mlp' (model.py:506-519): sigmoid(fc3(bn2(relu(fc2(bn1(relu(fc1([e_h | e_t])))))))) ."""
+        if not hasattr(self, "fc1"):
+            raise AttributeError("call initialize_MLP() first (model.py:499)")
+        self.gat_embed, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
+        eh = pruned.gather_rows(self.gat_embed, head_ids)
+        et = pruned.gather_rows(self.gat_embed, tail_ids)
+        c = eh.shape[1]
+        w1 = self.fc1.weight
+        x = ops.multi_linear((eh, et), (w1[:, :c], w1[:, c:]), self.fc1.bias)       # fc1 over [e_h | e_t], no cat
+        x = ops.relu_batchnorm(x, self.norm1)
+        x = ops.relu_batchnorm(ops.linear(x, self.fc2.weight, self.fc2.bias), self.norm2)
+        return torch.sigmoid(ops.linear(x, self.fc3.weight, self.fc3.bias))
+
     def get_final_embeddings(self, entity_ids):
         return self.gat_embeddings()[entity_ids]
 
@@ -394,6 +422,8 @@ class LiteralKG(nn.Module):
             return self.predict_links(*input)
         if mode == "fine_tuning":
             return self.calculate_prediction_loss(*input)
+        if mode == "mlp":
+            return self.train_MLP(*input)
         return None   # unknown modes fall through silently, as in the reference (model.py:521-532)
 
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):

@@ -497,6 +497,46 @@ def dot_loss(emb, h, pos_t, neg_t, lam):
     return _DotLoss.apply(emb, h, pos_t, neg_t, lam)
 
 
+# ----------------------------------------------------------------------------- f1 MLP head
+class _ReluBatchNorm(Function):
+    """y = BatchNorm1d(relu(z)) (model.py:515-516); updates the running buffers in training mode."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, training, momentum, eps):
+        _need_gpu(z, gamma, beta, running_mean, running_var)
+        z = _f32_rows(z)
+        n, d = z.shape
+        y = torch.empty((n, d), dtype=torch.float32, device=z.device)
+        mean = torch.empty(d, dtype=torch.float32, device=z.device)
+        invstd = torch.empty(d, dtype=torch.float32, device=z.device)
+        N.call("lkg_relu_batchnorm_fwd_f32", n, d, N.ptr(z), _ld(z), N.ptr(gamma), N.ptr(beta), float(eps),
+               int(training), float(momentum), N.ptr(running_mean), N.ptr(running_var), N.ptr(y), _ld(y),
+               N.ptr(mean), N.ptr(invstd), _stream())
+        ctx.save_for_backward(z, gamma, mean, invstd)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, gamma, mean, invstd = ctx.saved_tensors
+        gy = _f32_rows(gy)
+        n, d = z.shape
+        gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
+        gg = torch.empty(d, dtype=torch.float32, device=z.device)
+        gb = torch.empty(d, dtype=torch.float32, device=z.device)
+        N.call("lkg_relu_batchnorm_bwd_f32", n, d, N.ptr(z), _ld(z), N.ptr(gamma), N.ptr(mean), N.ptr(invstd),
+               int(ctx.training), N.ptr(gy), _ld(gy), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb), _stream())
+        return gz, gg, gb, None, None, None, None, None
+
+
+def relu_batchnorm(z, bn: "torch.nn.BatchNorm1d"):
+    """bn(relu(z)) with bn's parameters / buffers / mode; bumps num_batches_tracked like nn.BatchNorm1d."""
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _ReluBatchNorm.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, momentum, bn.eps)
+
+
 # ----------------------------------------------------------------------------- f1 heads
 def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     """table[ids] without autograd (inference heads, model.py:475-476)."""

@@ -245,9 +245,54 @@ def loader_laplacian_case(name, n, h, t, r):
     save(name, **out)
 
 
+def mlp_case(cls, name, args, n, h, t, r, seed, rng, init_mlp):
+    """mode='mlp' (model.py:499-519 / model_bce.py:423-436): train-mode forward (BatchNorm batch statistics, running
+    buffers updated), BCE backward as main_finetuning_BCE.py does, then an eval-mode forward."""
+    n_rel = int(r.max()) + 1
+    a_in = laplacian(n, h, t, r)
+    m = build(cls, args, n, n_rel, a_in, None, None, seed)
+    if init_mlp:
+        torch.manual_seed(seed + 1)
+        m.initialize_MLP()
+    with torch.no_grad():
+        for bn in (m.norm1, m.norm2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.1)
+    init = sd_to_np(m.state_dict())
+    heads = torch.from_numpy(rng.integers(0, n, 96))
+    tails = torch.from_numpy(rng.integers(0, n, 96))
+    labels = torch.from_numpy((rng.random(96) > 0.5).astype(np.float32))
+    dev = torch.device("cpu")
+    m.train()
+    out = m(heads, tails, device=dev, mode="mlp").reshape(-1)
+    loss = torch.nn.functional.binary_cross_entropy(out, labels)
+    loss.backward()
+    grads = {"g/" + k_: v.grad.detach().numpy().copy() for k_, v in m.named_parameters()
+             if v.grad is not None and k_ != "A_in"}
+    after = {"after/" + k_: v.detach().numpy().copy() for k_, v in m.state_dict().items() if "running" in k_ or "tracked" in k_}
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(heads, tails, device=dev, mode="mlp").reshape(-1)
+    arrs = dict(cfg=np.array(json.dumps(args)), n=np.int64(n), n_rel=np.int64(n_rel), h=h, t=t, r=r,
+                a_indices=a_in.indices().numpy(), a_values=a_in.values().numpy(), heads=heads.numpy(),
+                tails=tails.numpy(), labels=labels.numpy(), out_train=out.detach().numpy(), loss=loss.detach().numpy(),
+                out_eval=out_eval.numpy(), init_mlp=np.bool_(init_mlp))
+    arrs.update(init)
+    arrs.update(grads)
+    arrs.update(after)
+    save(name, **arrs)
+
+
 def main():
     ref_model, ref_model_bce = ref_modules()
     rng = np.random.default_rng(2022)
+    if "--only-mlp" in sys.argv:
+        rng = np.random.default_rng(515)
+        mh, mt, mr = random_graph(rng, 220, 1500, 4, 6)
+        mlp_case(ref_model.LiteralKG, "mlp_model_gcn_l1_scale", make_args(scale_gat_dim=24), 220, mh, mt, mr, 61, rng, True)
+        mlp_case(ref_model_bce.LiteralKG, "mlp_bce_gcn_l2_scale", make_args(scale_gat_dim=16, n_conv_layers=2), 220, mh,
+                 mt, mr, 62, rng, False)
+        return
     if "--only-laplacian" in sys.argv:
         rng = np.random.default_rng(4242)
         lh, lt, lr = random_graph(rng, 260, 2600, 5, 10)       # (h,r,t) distinct, some (h,t) under two relations

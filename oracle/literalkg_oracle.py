@@ -341,3 +341,17 @@ def laplacian_a_in(n_entities: int, h: torch.Tensor, t: torch.Tensor, r: torch.T
     acc = acc.coalesce()
     keep = acc.values() != 0          # scipy's diagonal products do not store the inf -> 0 entries
     return torch.sparse_coo_tensor(acc.indices()[:, keep], acc.values()[keep].float(), acc.shape).coalesce()
+
+
+# --------------------------------------------------------------------------
+# f1  MLP pair head                   model.py:499-519, model_bce.py:423-436
+# --------------------------------------------------------------------------
+def mlp_head(p: Params, gat: torch.Tensor, head_ids, tail_ids, training: bool = True) -> torch.Tensor:
+    """sigmoid(fc3(bn2(relu(fc2(bn1(relu(fc1([e_h | e_t]))))))));  training=True uses batch statistics (the running
+    buffers in ``p`` are updated in place like nn.BatchNorm1d does)."""
+    x = torch.cat([gat[head_ids], gat[tail_ids]], dim=1)
+    for fc, bn in (("fc1", "norm1"), ("fc2", "norm2")):
+        x = torch.relu(F.linear(x, p[fc + ".weight"], p[fc + ".bias"]))
+        x = F.batch_norm(x, p[bn + ".running_mean"], p[bn + ".running_var"], p[bn + ".weight"], p[bn + ".bias"],
+                         training, 0.1, 1e-5)
+    return torch.sigmoid(F.linear(x, p["fc3.weight"], p["fc3.bias"]))

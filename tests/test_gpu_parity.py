@@ -808,3 +808,42 @@ def test_runs_under_autograd_anomaly_mode(L, gpu_device):
         loss.backward()
     np.testing.assert_allclose(loss.item(), float(gd["loss"]), rtol=1e-5)
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)
+
+
+# ----------------------------------------------------------------------------- f1 MLP head (mode='mlp')
+@pytest.mark.parametrize("name", golden_names("mlp_"))
+def test_mlp_head_matches_reference_fixture(L, gpu_device, name):
+    gd = load_golden(name)
+    scoring = "transr" if bool(gd["init_mlp"]) else "transe"      # model.py builds the head on demand, model_bce.py in its ctor
+    cfg = golden_cfg(gd)
+    n = int(gd["n"])
+    a_in = torch.sparse_coo_tensor(torch.from_numpy(gd["a_indices"]), torch.from_numpy(gd["a_values"]), (n, n)).coalesce()
+    m = L.LiteralKG(cfg, n, int(gd["n_rel"]), a_in, scoring=scoring)
+    if scoring == "transr":
+        with pytest.raises(AttributeError, match="initialize_MLP"):
+            m.train_MLP(torch.zeros(2, dtype=torch.long), torch.zeros(2, dtype=torch.long))
+        m.initialize_MLP()
+    params = golden_params(gd)
+    res = m.load_state_dict(params, strict=False)
+    assert res.missing_keys == ["A_in"] and not res.unexpected_keys, res          # same keys as the reference
+    m.to(gpu_device).train()
+    heads, tails = (torch.from_numpy(gd[k]).to(gpu_device) for k in ("heads", "tails"))
+    out = m(heads, tails, device=gpu_device, mode="mlp")
+    assert out.shape == (96, 1)
+    np.testing.assert_allclose(out.detach().cpu().numpy().reshape(-1), gd["out_train"], rtol=1e-4, atol=1e-5)
+    loss = torch.nn.functional.binary_cross_entropy(out.reshape(-1), torch.from_numpy(gd["labels"]).to(gpu_device))
+    np.testing.assert_allclose(loss.item(), float(gd["loss"]), rtol=1e-5)
+    loss.backward()
+    grads = {k: v.grad for k, v in m.named_parameters() if v.grad is not None}
+    for k, want in gd.items():
+        if k.startswith("g/"):
+            assert k[2:] in grads, k
+            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+    sd = m.state_dict()
+    for k, want in gd.items():
+        if k.startswith("after/"):                               # running statistics and the batch counter
+            np.testing.assert_allclose(sd[k[6:]].cpu().numpy(), want, rtol=1e-4, atol=1e-6, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(heads, tails, device=gpu_device, mode="mlp")
+    np.testing.assert_allclose(out_eval.cpu().numpy().reshape(-1), gd["out_eval"], rtol=1e-4, atol=1e-5)

@@ -144,3 +144,24 @@ def test_c_oracle_spmm(name):
     x = g["p/entity_embed.weight"]
     got = c_oracle.spmm(np.cumsum(rowptr), g["a_indices"][1], g["a_values"], x)
     np.testing.assert_allclose(got, O.aggregate(a, torch.from_numpy(x)).numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("mlp_"))
+def test_mlp_head(name):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in golden_params(g).items()}
+    gat = O.gat_embeddings(p, cfg, _a_in(g))
+    heads, tails = torch.from_numpy(g["heads"]), torch.from_numpy(g["tails"])
+    out = O.mlp_head(p, gat, heads, tails, training=True).reshape(-1)
+    np.testing.assert_allclose(out.detach().numpy(), g["out_train"], rtol=TOL, atol=1e-6)
+    loss = torch.nn.functional.binary_cross_entropy(out, torch.from_numpy(g["labels"]))
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=TOL)
+    loss.backward()
+    for k, v in g.items():
+        if k.startswith("g/"):
+            np.testing.assert_allclose(p[k[2:]].grad.numpy(), v, rtol=1e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(p["norm1.running_var"].numpy(), g["after/norm1.running_var"], rtol=1e-5)
+    with torch.no_grad():
+        out_eval = O.mlp_head(p, O.gat_embeddings(p, cfg, _a_in(g)), heads, tails, training=False).reshape(-1)
+    np.testing.assert_allclose(out_eval.numpy(), g["out_eval"], rtol=TOL, atol=1e-6)
