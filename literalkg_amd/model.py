@@ -229,6 +229,7 @@ class LiteralKG(nn.Module):
         # opt-in: evaluate every layer only on the rows the batch needs (exact, see pruned.py); then
         # self.gat_embed holds the rows self.gat_rows instead of all N
         self.prune_to_batch = bool(getattr(args, "prune_to_batch", False))
+        self.prune_max_fraction = 0.5     # frontier larger than this share of the entities: the dense path is cheaper
         self.gat_rows = None
         self._att: Optional[AttentionCSR] = None
         self._att_key = None
@@ -299,9 +300,12 @@ class LiteralKG(nn.Module):
 
     def gat_embeddings_for(self, ids: torch.Tensor):
         """Rows `unique(ids)` of gat_embeddings(), computed on the batch's L-hop frontier only (pruned.py).
-        Returns (compact table, BatchSubgraph)."""
+        Returns (compact table, BatchSubgraph), or (None, None) when the frontier covers more than
+        ``prune_max_fraction`` of the entities (large batches x many layers: the dense path is cheaper then)."""
         att = self._attention()
         sub = pruned.build_batch_subgraph(att.graph, att.val, ids, self.n_layers)
+        if sub.rows[0].numel() > self.prune_max_fraction * self.n_entities:
+            return None, None
         top = self.n_layers
         num, txt = self._literals()
         r0 = sub.rows[0]
@@ -328,6 +332,9 @@ class LiteralKG(nn.Module):
             self.gat_rows = None
             return self.gat_embeddings(), id_lists
         table, sub = self.gat_embeddings_for(torch.cat([i.reshape(-1) for i in id_lists]))
+        if table is None:
+            self.gat_rows = None
+            return self.gat_embeddings(), id_lists
         self.gat_rows = sub.rows[-1]
         return table, tuple(sub.positions(i) for i in id_lists)
 

@@ -698,6 +698,17 @@ def test_pruned_trajectory_matches_reference(L, gpu_device):
                                atol=2e-5)
 
 
+def test_pruning_falls_back_when_the_frontier_is_large(L, gpu_device):
+    gd = load_golden("encoder_gcn_l2_scale")
+    m = _build_model(L, gd, gpu_device, "transr")
+    m.prune_to_batch = True
+    m.prune_max_fraction = 0.05                     # the 2-hop frontier of 120 triples covers far more than 5 %
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    assert m.gat_rows is None and m.gat_embed.shape[0] == int(gd["n"])
+    np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
+
+
 def test_gin_ignores_prune_flag(L, gpu_device):
     gd = load_golden("encoder_gin_l2")
     m = _build_model(L, gd, gpu_device, "transr")

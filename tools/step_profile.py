@@ -24,6 +24,9 @@ dev = torch.device("cuda:0")
 cfgs = {
     "c2": dict(embed_dim=128, relation_dim=128, conv_dim=128, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "c3": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=2, use_num_lit=True, use_txt_lit=True),
+    # BASELINE config[4] shape on one GPU (scale the graph with --n/--e): D=512, 3 layers, TransR, K=256 negatives
+    "c5": dict(embed_dim=512, relation_dim=512, conv_dim=512, n_conv_layers=3, use_num_lit=False, use_txt_lit=False,
+               pre_training_neg_rate=256),
 }
 base = dict(use_pretrain=0, device=dev, scale_gat_dim=None, use_residual=False, alpha=0.1, lamda=0.5,
             aggregation_type=args.agg, mess_dropout=0.0, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
@@ -49,7 +52,8 @@ t0 = time.perf_counter()
 model(hd, td, rd, list(range(16)), device=dev, mode="update_att"); torch.cuda.synchronize()
 print(f"first update_att incl. host CSR build: {(time.perf_counter()-t0)*1e3:.0f} ms")
 ua = sync_time(lambda: model(hd, td, rd, list(range(16)), device=dev, mode="update_att"))
-bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3))
+k_neg = cfg.pre_training_neg_rate
+bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, 683 if k_neg == 3 else 128, k_neg))
 if args.fused_adam:
     from literalkg_amd.optim import Adam
     opt = Adam(model.parameters(), lr=1e-4)
