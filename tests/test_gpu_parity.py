@@ -654,6 +654,7 @@ def test_pruned_step_matches_reference_fixture(L, gpu_device, name):
     form = str(gd["form"])
     m = _build_model(L, gd, gpu_device, form)
     m.prune_to_batch = True
+    m.prune_max_fraction = 1.0                     # tiny fixture graph: keep the compact path even at ~100 % coverage
     batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
     loss = m(*batch, device=gpu_device, mode="pre_training")
     assert m.gat_rows is not None and m.gat_embed.shape[0] == m.gat_rows.numel() < int(gd["n"])
@@ -683,6 +684,7 @@ def test_pruned_trajectory_matches_reference(L, gpu_device):
     gd = load_golden("trajectory_gcn_l2_gatemul_scale")
     m = _build_model(L, gd, gpu_device, "transr")
     m.prune_to_batch = True
+    m.prune_max_fraction = 1.0
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=float(gd["lr"]))
     h, t, r = (torch.from_numpy(gd[k]).to(gpu_device) for k in "htr")
