@@ -1,0 +1,94 @@
+"""GPU: the two multi-GPU schemes of literalkg_amd/sharding.py with the REAL HIP SpMM, rehearsed as 2 ranks sharing
+the one GPU of the test box over gloo (host-staged exchange).  Each rank checks its slab / row range against the
+single-device result it computes itself.  (RCCL itself needs several GPUs; the driver's scaling run exercises it.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import literalkg_amd as L
+        from literalkg_amd import ops
+        from literalkg_amd.sharding import FeatureShardedAggregation, ShardedAggregation, shard_bounds
+        from literalkg_amd.synth import make_kg
+        dev = torch.device("cuda:0")
+        n, e, d = 30_000, 400_000, 128
+        h, t, r = make_kg(n, e, seed=3)
+        g = L.KGStructure.from_triples(n, h, t, r, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(1)
+        ent = torch.randn((n, d), generator=gen, device=dev) * 0.2
+        rel = torch.randn((16, d), generator=gen, device=dev) * 0.2
+        gside = torch.randn((n, d), generator=gen, device=dev)
+        val, _ = ops.edge_softmax(g, ent, rel)
+        want_side = ops.spmm_raw(g.rowptr, g.col, val, ent, n, long_rows=g.long_rows(False))
+        want_grad = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), gside, n,
+                                 long_rows=g.long_rows(True))
+        cuts = shard_bounds(g, world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        ok = True
+        # --- feature sharding: slab forward (+ pipelined exchange), exchange back, slab backward
+        fs = FeatureShardedAggregation(g, val, rank, world, d, cuts)
+        cols = slice(rank * fs.dg, (rank + 1) * fs.dg)
+        side_slab, block = fs.forward_to_row_block(fs.column_slab(ent))
+        ok &= torch.allclose(side_slab, want_side[:, cols], rtol=1e-5, atol=1e-5)
+        rows = torch.cat([block[i] for i in range(world)], dim=1)
+        ok &= torch.allclose(rows, want_side[lo:hi], rtol=1e-5, atol=1e-5)
+        ok &= torch.equal(fs.to_row_block(side_slab), block)
+        gblock = torch.stack([gside[lo:hi, i * fs.dg:(i + 1) * fs.dg] for i in range(world)]).contiguous()
+        gslab = fs.to_column_slab(gblock)
+        ok &= torch.equal(gslab, gside[:, cols].contiguous())
+        ok &= torch.allclose(fs.backward(gslab), want_grad[:, cols], rtol=1e-5, atol=1e-4)
+        # --- row-range sharding: own rows forward, all-reduced transpose backward (attention computed per shard)
+        keep = (h >= lo) & (h < hi)
+        mine = L.KGStructure.from_triples(n, h[keep], t[keep], r[keep], device=dev)
+        val_mine, _ = ops.edge_softmax(mine, ent, rel, row_lo=lo, row_hi=hi)
+        rp = g.host("rowptr")
+        ok &= torch.allclose(val_mine, val[rp[lo]:rp[hi]], rtol=1e-5, atol=1e-7)
+        sh = ShardedAggregation(mine, val_mine, lo, hi, n_chunks=3)
+        ok &= torch.allclose(sh.forward(ent), want_side[lo:hi], rtol=1e-5, atol=1e-5)
+
+        def staged_all_reduce(x, op=None, group=None, async_op=False):      # gloo moves host memory only
+            hx = x.cpu()
+            _orig(hx, op=dist.ReduceOp.SUM, group=group)
+            x.copy_(hx)
+            return type("W", (), {"wait": lambda self: None})()
+        _orig = dist.all_reduce
+        dist.all_reduce = staged_all_reduce
+        try:
+            grad = sh.backward(gside[lo:hi].contiguous())
+        finally:
+            dist.all_reduce = _orig
+        ok &= torch.allclose(grad, want_grad, rtol=1e-5, atol=1e-4)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_on_one_gpu(gpu_device):
+    import __graft_entry__ as ge
+    ge.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)], res
