@@ -222,11 +222,17 @@ def main():
     ent = xavier_table(n_glob, d, dev, seed=2022)              # same table on every rank
     relemb = xavier_table(16, d, dev, seed=7)
     ev_n = 3
+
+    def expected_rows(val_for, rows):
+        """side[rows] recomputed one row at a time from the full table (spot check of the sharded result)."""
+        return torch.cat([ops.spmm_raw(g.rowptr[i:i + 2], g.col, val_for, ent, 1) for i in rows])
+    probe = [lo + int(x) for x in np.random.default_rng(rank).integers(0, n_loc, 8)]
     if mode == "features":
         # real attention values for the whole graph (replicated, like the structure)
         val, _ = ops.edge_softmax(g, ent, relemb)
         fs = FeatureShardedAggregation(g, val, rank, world, d, [i * n_loc for i in range(world + 1)])
         slab = fs.column_slab(ent)
+        want_probe = expected_rows(val, probe)
         del ent
         dg = fs.dg
         side_slab = torch.empty((n_glob, dg), device=dev)
@@ -258,6 +264,7 @@ def main():
     else:
         val, _ = ops.edge_softmax(g, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
         shard = ShardedAggregation(g, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
+        want_probe = expected_rows(val, probe)
         grad_side = torch.randn((hi - lo, d), device=dev)
         side = torch.empty((hi - lo, d), device=dev)
         grad_table = torch.empty((n_glob, d), device=dev)
@@ -273,8 +280,14 @@ def main():
             if ev is not None:
                 ev[2].record()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         step()
+    # spot check: 8 of this rank's output rows (after the exchange, in feature mode) against a direct evaluation
+    if mode == "features":
+        got_probe = torch.cat([row_block[:, i - lo, :].reshape(1, -1) for i in probe])
+    else:
+        got_probe = side[[i - lo for i in probe]]
+    valid = torch.tensor([float(torch.allclose(got_probe, want_probe, rtol=1e-4, atol=1e-6))])
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(ev_n)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
@@ -290,8 +303,9 @@ def main():
     nnz_all = torch.tensor([g.nnz], dtype=torch.int64)
     if world > 1:
         cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        el, nnz_all = el.to(cdev), nnz_all.to(cdev)
+        el, nnz_all, valid = el.to(cdev), nnz_all.to(cdev), valid.to(cdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(valid, op=dist.ReduceOp.MIN)
         if mode == "rows":
             dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
     elapsed = float(el)
@@ -328,6 +342,7 @@ def main():
                                          f"all-to-all exchange"}[mode],
                 "skew": args.skew,
                 "host_graph_build_s": round(t_build, 2),
+                "spot_check": "ok" if float(valid) == 1.0 else "MISMATCH: 8 output rows per rank differ from a direct evaluation",
             },
             "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel (forward launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
