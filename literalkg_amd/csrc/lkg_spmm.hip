@@ -225,8 +225,13 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     LKG_REQUIRE(!self || ld_self >= d, "lkg_spmm_csr_f32: self stride %lld smaller than d=%d", (long long)ld_self, d);
     const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out) &&
                      (!self || (ld_self % 4 == 0 && lkg_aligned16(self)));
-    const int width = vec ? 4 : 1;
-    const int block_cols = 256 * width;   // columns one launch covers (CPL <= 4)
+    // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
+    // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
+    // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
+    // flight and a 128-column slab of the source table is 2-4x more likely to be served from the 256 MiB
+    // Infinity Cache -- at the price of re-reading the (col, val) stream once per slab (+8 B per entry per slab).
+    // The scalar (unaligned) path keeps up to 256 columns per launch.
+    const int block_cols = vec ? 128 : 256;
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,

@@ -35,7 +35,15 @@ for skew in ("zipf", "uniform"):
         ms = np.array([a.elapsed_time(b) for a, b in ev])
         return np.median(ms), ms.min()
     out = torch.empty((args.n, d), device=dev)
-    for name, fn in [
+    def slabs(k):
+        w = d // k
+        def run():
+            for i in range(k):
+                ops.spmm_raw(g.rowptr, g.col, val, x[:, i * w:(i + 1) * w], args.n, out=out[:, i * w:(i + 1) * w],
+                             long_rows=g.long_rows(False))
+        return run
+    extra = [(f"fwd in {k} column slabs   ", slabs(k)) for k in (2, 4) if d % (4 * k) == 0 and d // k >= 32]
+    for name, fn in extra + [
         ("fwd wave-per-row      ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out)),
         ("fwd + long-row blocks ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
         ("bwd wave-per-row      ", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out)),
