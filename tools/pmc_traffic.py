@@ -4,7 +4,7 @@ the forward SpMM.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM se
 counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) read -> x2;
 WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Separate --pmc passes (TCC slots).
    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [gpurun_out/pmc_tcc] > profiles/rNN_pmc_traffic.json"""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 
 def per_dispatch(d, kernel="spmm_csr_kernel"):
     f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
@@ -14,16 +14,25 @@ def per_dispatch(d, kernel="spmm_csr_kernel"):
             acc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["Grid_Size"])))
     return {k: sorted(v) for k, v in acc.items()}
 
+# one lkg_spmm_csr_f32 call = SLABS kernel launches (128-column slabs: 2 at D=256); bench.py alternates forward and
+# backward calls, so the dispatches come as [fwd x SLABS, bwd x SLABS, ...]
+SLABS = int(os.environ.get("LKG_SLABS", "2"))
+
+
+def per_call(rows):
+    full = max(g for _, _, g in rows)                 # bench.py's spot check launches a few one-row grids: skip them
+    vals = [v for _, v, g in rows if g > full // 2]
+    calls = [sum(vals[i:i + SLABS]) for i in range(0, len(vals) - SLABS + 1, SLABS)]
+    return calls[0::2], calls[1::2]
+
+
 fetch = per_dispatch(sys.argv[1])["FETCH_SIZE"]
 write = per_dispatch(sys.argv[2])["WRITE_SIZE"]
-# bench.py alternates forward / backward launches of the same kernel: even positions are forwards
-fwd_f = [v for i, (_, v, _) in enumerate(fetch) if i % 2 == 0]
-fwd_w = [v for i, (_, v, _) in enumerate(write) if i % 2 == 0]
-bwd_f = [v for i, (_, v, _) in enumerate(fetch) if i % 2 == 1]
-bwd_w = [v for i, (_, v, _) in enumerate(write) if i % 2 == 1]
+fwd_f, bwd_f = per_call(fetch)
+fwd_w, bwd_w = per_call(write)
 mean = lambda x: sum(x) / len(x)
 out = {
-    "kernel": "spmm_csr_kernel<float4,64,1,4,true>", "launches_sampled": len(fwd_f),
+    "kernel": f"spmm_csr_kernel<float4,32,1,4,true> x {SLABS} column slabs per call", "calls_sampled": len(fwd_f),
     "FETCH_SIZE_KiB_fwd": mean(fwd_f), "WRITE_SIZE_KiB_fwd": mean(fwd_w),
     "FETCH_SIZE_KiB_bwd": mean(bwd_f), "WRITE_SIZE_KiB_bwd": mean(bwd_w),
     "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
