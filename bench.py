@@ -350,7 +350,11 @@ def main():
                          "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
                          "bwd_launch_ms": float(bwd_ms.mean()),
                          "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if mode != "rows" else None,
-                         "exchange_ms": float(xch_ms.mean()) if xch_ms is not None else None},
+                         "exchange_ms": float(xch_ms.mean()) if xch_ms is not None else None,
+                         "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (its "
+                                 "128-column slab launches together); it can exceed the ~6.3 TB/s of a plain HBM copy "
+                                 "because slabs of the source table are partly served from the 256 MiB Infinity Cache, "
+                                 "whose hits the fabric-side FETCH_SIZE counter (traffic) still counts"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, val, n_glob, d, 2022)
