@@ -120,11 +120,13 @@ class FeatureShardedAggregation:
         return self.spmm(g.t_rowptr, g.t_col, self.val_t, grad_slab, g.n, out=out, long_rows=g.long_rows(True))
 
     def forward_to_row_block(self, slab: torch.Tensor, side_slab: Optional[torch.Tensor] = None,
-                             out: Optional[torch.Tensor] = None):
-        """forward() fused with to_row_block(): the SpMM runs head-row range by head-row range, and as soon as
-        the rows owned by rank j are done their block leaves for rank j (point-to-point, RCCL's stream) while the
-        next range is being aggregated -- the all-to-all hides behind the SpMM except for its last round.
-        Round k computes the rows of rank (rank + k) % G and receives this rank's rows from rank (rank - k) % G.
+                             out: Optional[torch.Tensor] = None, pieces: int = 4):
+        """forward() fused with to_row_block(): the SpMM runs head-row range by head-row range, and as soon as a
+        piece of the rows owned by rank j is done it leaves for rank j (point-to-point, RCCL's stream, one xGMI
+        link per peer) while the next piece is being aggregated.  Every peer's range is cut into `pieces` parts
+        and the parts are visited peer-major inside a part index, so all 7 links are busy from the first round
+        on and only the LAST part of one peer (1 / (G * pieces) of the traffic) is exposed after the SpMM ends.
+        Part p of round k computes rows of rank (rank + k) % G and receives from rank (rank - k) % G.
         Returns (side_slab [N, D/G], row_block [G, rows_g, D/G])."""
         g = self.graph
         if side_slab is None:
@@ -132,26 +134,41 @@ class FeatureShardedAggregation:
         if out is None:
             out = torch.empty((self.world, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
         staged = slab.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"   # host-only transport
+
+        def part(lo, hi, p):      # p-th of `pieces` sub-ranges of [lo, hi)
+            n = hi - lo
+            return lo + n * p // pieces, lo + n * (p + 1) // pieces
+
         works, host = [], []
-        for k in range(self.world):
-            j, i = (self.rank + k) % self.world, (self.rank - k) % self.world
-            lo, hi = self.cuts[j], self.cuts[j + 1]
-            rows = side_slab[lo:hi]
-            self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=rows, long_rows=g.long_rows(False, lo, hi))
-            if k == 0:
-                out[self.rank].copy_(rows)
-                continue
-            if staged:
-                snd, rcv = rows.cpu(), torch.empty(out[i].shape, dtype=out.dtype)
-                host.append((rcv, i))
-            else:
-                snd, rcv = rows, out[i]
-            works += dist.batch_isend_irecv([dist.P2POp(dist.isend, snd, j, self.group),
-                                             dist.P2POp(dist.irecv, rcv, i, self.group)])
+        for p in range(pieces):
+            for k in range(self.world):
+                j, i = (self.rank + k) % self.world, (self.rank - k) % self.world
+                lo, hi = part(self.cuts[j], self.cuts[j + 1], p)
+                if hi > lo:
+                    self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=side_slab[lo:hi],
+                              long_rows=g.long_rows(False, lo, hi))
+                if k == 0:
+                    mlo, mhi = part(0, self.my_rows, p)
+                    out[self.rank, mlo:mhi].copy_(side_slab[lo:hi])
+                    continue
+                rlo, rhi = part(0, self.my_rows, p)          # the matching part of MY rows, arriving from rank i
+                ops_ = []
+                if hi > lo:
+                    snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
+                    ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
+                if rhi > rlo:
+                    if staged:
+                        rcv = torch.empty((rhi - rlo, self.dg), dtype=out.dtype)
+                        host.append((rcv, i, rlo, rhi))
+                    else:
+                        rcv = out[i, rlo:rhi]
+                    ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
+                if ops_:
+                    works += dist.batch_isend_irecv(ops_)
         for w in works:
             w.wait()
-        for rcv, i in host:
-            out[i].copy_(rcv)
+        for rcv, i, rlo, rhi in host:
+            out[i, rlo:rhi].copy_(rcv)
         return side_slab, out
 
     def to_row_block(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
