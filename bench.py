@@ -80,7 +80,7 @@ def cpu_baseline(g, val, n, d, seed):
 def whole_path_timings(h, t, r, n, d, dev):
     """Context numbers for the same graph (SURVEY.md 8d ii-iv), outside the headline metric: the drop-in
     module's update_att, and one pre_training step (1 gcn layer, D=d, TransR, 2049 triples) forward /
-    forward+backward.  Median of 5 after 2 warm-ups, host-timed around a device sync."""
+    forward+backward.  Median of 10 after 3 warm-ups, host-timed around a device sync."""
     from types import SimpleNamespace
     import literalkg_amd as L
     from literalkg_amd.synth import make_batch
@@ -93,8 +93,8 @@ def whole_path_timings(h, t, r, n, d, dev):
     hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
     batch = [torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3)]
 
-    def timed(fn, reps=5):
-        for _ in range(2):
+    def timed(fn, reps=10):
+        for _ in range(3):
             fn()
         ms = []
         for _ in range(reps):
