@@ -282,6 +282,14 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 
+/* Small element-wise steps of the layers (row-major n x d, row strides in elements):
+ *   op 0  out = alpha * a + beta * b   (b NULL: alpha * a + beta)   GCNII residual mix, model.py:94-96; 'gin' sums
+ *   op 1  out = a * b                                                ego * side of 'bi-interaction', model.py:127
+ *   op 2  out = leaky(a, alpha) + leaky(b, alpha)  (b NULL: one term) model.py:125-130, 310
+ *   op 3  out = a * (b > 0 ? 1 : alpha)                              LeakyReLU backward (a gradient, b pre-activation) */
+int lkg_eltwise_f32(int32_t op, int64_t n, int32_t d, const float *a, int64_t lda, const float *b,
+                    int64_t ldb, float alpha, float beta, float *out, int64_t ldo, void *stream);
+
 /* f4  one fused Adam step over a dense contiguous tensor (the reference runs dense torch.optim.Adam over
  * the N x D entity table every step, main_pretraining.py:47,119): torch.optim.Adam's arithmetic,
  * `step` is the 1-based step count used for the bias corrections; weight_decay is the L2 form.          */

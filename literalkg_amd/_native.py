@@ -48,6 +48,7 @@ PROTOTYPES = {
     "lkg_gate_blend_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp],
     "lkg_colsum_f32": [i64, i32, vp, i64, vp, vp],
+    "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],
     "lkg_adam_step_f32": [i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp],
 }
 _RESTYPE = {"lkg_last_error": C.c_char_p}

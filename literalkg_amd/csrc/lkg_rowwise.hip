@@ -647,3 +647,72 @@ extern "C" int lkg_relu_batchnorm_bwd_f32(int64_t n, int32_t d, const float *z, 
     LKG_CHECK_LAUNCH("lkg_relu_batchnorm_bwd_f32");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Small element-wise steps of the aggregation layers that are not worth a fusion of their own: the GCNII residual
+// mix (model.py:94-96), ego * side and the per-branch LeakyReLU sum of 'bi-interaction' (model.py:125-130), the
+// row sums of 'gin' (model.py:146, 158), LeakyReLU after linear_gat (model.py:310).  One strided 2-D kernel,
+// 2^k threads per row like the gate blend, 16-byte accesses when rows are aligned.
+//   op 0  out = alpha * a + beta * b          (b == NULL: out = alpha * a + beta)
+//   op 1  out = a * b
+//   op 2  out = leaky(a, alpha) + leaky(b, alpha)          (b == NULL: out = leaky(a, alpha))
+//   op 3  out = a * (b > 0 ? 1 : alpha)       (LeakyReLU backward: a = upstream gradient, b = pre-activation)
+namespace {
+template <int W>
+__global__ __launch_bounds__(256) void eltwise_kernel(int op, long n, int d, int log_tpr, const float *__restrict__ a,
+                                                       long lda, const float *__restrict__ b, long ldb, float alpha,
+                                                       float beta, float *__restrict__ out, long ldo) {
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c0 = (threadIdx.x & (tpr - 1)) * W;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+        for (int c = c0; c < d; c += tpr * W) {
+            float av[W], bv[W], ov[W];
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(av) = *reinterpret_cast<const float4 *>(a + r * lda + c);
+                if (b) *reinterpret_cast<float4 *>(bv) = *reinterpret_cast<const float4 *>(b + r * ldb + c);
+            } else {
+                av[0] = a[r * lda + c];
+                if (b) bv[0] = b[r * ldb + c];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float x = av[k], y = b ? bv[k] : 0.f;
+                float o;
+                if (op == 0)
+                    o = b ? fmaf(alpha, x, beta * y) : fmaf(alpha, x, beta);
+                else if (op == 1)
+                    o = x * y;
+                else if (op == 2)
+                    o = (x > 0.f ? x : alpha * x) + (b ? (y > 0.f ? y : alpha * y) : 0.f);
+                else
+                    o = x * (y > 0.f ? 1.f : alpha);
+                ov[k] = o;
+            }
+            if constexpr (W == 4)
+                *reinterpret_cast<float4 *>(out + r * ldo + c) = *reinterpret_cast<float4 *>(ov);
+            else
+                out[r * ldo + c] = ov[0];
+        }
+}
+}  // namespace
+
+extern "C" int lkg_eltwise_f32(int32_t op, int64_t n, int32_t d, const float *a, int64_t lda, const float *b,
+                               int64_t ldb, float alpha, float beta, float *out, int64_t ldo, void *stream) {
+    LKG_REQUIRE(op >= 0 && op <= 3, "lkg_eltwise_f32: unknown op %d", op);
+    LKG_REQUIRE(n >= 0 && d > 0 && lda >= d && ldo >= d && (!b || ldb >= d), "lkg_eltwise_f32: bad sizes");
+    LKG_REQUIRE(b || (op != 1 && op != 3), "lkg_eltwise_f32: op %d needs two operands", op);
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(a && out, "lkg_eltwise_f32: null pointer");
+    const bool vec = d % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (!b || ldb % 4 == 0) && lkg_aligned16(a) &&
+                     lkg_aligned16(out) && (!b || lkg_aligned16(b));
+    const int lt = log_threads_per_row(vec ? d / 4 : d);
+    const int64_t blocks = std::min<int64_t>((n + (256 >> lt) - 1) / (256 >> lt), 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(eltwise_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, op, (long)n, d, lt,
+                           a, (long)lda, b, (long)ldb, alpha, beta, out, (long)ldo);
+    else
+        hipLaunchKernelGGL(eltwise_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, op, (long)n, d, lt,
+                           a, (long)lda, b, (long)ldb, alpha, beta, out, (long)ldo);
+    LKG_CHECK_LAUNCH("lkg_eltwise_f32");
+    return LKG_OK;
+}

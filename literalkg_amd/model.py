@@ -19,7 +19,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops, pruned
 from .gate import Gate, GateMul
@@ -95,9 +94,9 @@ class Aggregator(nn.Module):
         if not self.use_residual:
             return hi
         h0p = ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
-        mixed = (1 - alpha) * hi + alpha * h0p
+        mixed = ops.axpby(hi, h0p, 1 - alpha, alpha)
         beta = math.log(lamda / l + 1)
-        return ops.matmul(mixed, (1 - beta) + beta * self.weight)
+        return ops.matmul(mixed, ops.axpby(self.weight, None, beta, 1 - beta))
 
     @staticmethod
     def _lin(mod: nn.Linear, x):
@@ -112,7 +111,7 @@ class Aggregator(nn.Module):
             inner, _ = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=False)
             z = inner
             for e in extra_sum:
-                z = z + e
+                z = ops.axpby(z, e)
             slope = 1.0   # the second LayerNorm has no activation in front: slope 1 = identity
         y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p, yn_out=self.norm_out)
         self.last_normalized = yn
@@ -139,11 +138,10 @@ class Aggregator(nn.Module):
             return self._finish(z)
         if kind == "bi-interaction":
             s = self._lin(self.linear1, self.residual_connection(ego + side, h0, lamda, alpha, l))
-            b = self._lin(self.linear2, self.residual_connection(ego * side, h0, lamda, alpha, l))
-            # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): do it here, then a
-            # slope-1 epilogue for the LayerNorm
-            z = F.leaky_relu(b, ops.LEAKY_SLOPE) + F.leaky_relu(s, ops.LEAKY_SLOPE)
-            return self._finish(z, slope=1.0)
+            b = self._lin(self.linear2, self.residual_connection(ops.mul(ego, side), h0, lamda, alpha, l))
+            # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): one kernel, then a slope-1
+            # epilogue for the LayerNorm
+            return self._finish(ops.leaky_relu_sum(b, s), slope=1.0)
         raise NotImplementedError(kind)
 
     def _gin(self, ego, ego_plus_side, h0, all_layers, lamda, alpha, l):
@@ -155,7 +153,7 @@ class Aggregator(nn.Module):
         h = self._lin(self.inp_linear, ego_plus_side)
         for lin, norm in zip(self.linears, self.mlp_layer_norms):
             h, _ = ops.act_layernorm(self._lin(lin, h), norm.weight, norm.bias, want_norm=False)
-            stack = stack + h
+            stack = ops.axpby(stack, h)
         x = self.residual_connection(stack, h0, lamda, alpha, l)
         z = self._lin(self.out_linear, x)
         if len(all_layers) > 1:
@@ -291,7 +289,7 @@ class LiteralKG(nn.Module):
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused
         cat = ops.assemble_cat(cb, kept)
         if self.scale_gat_dim is not None:
-            return F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
+            return ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
         return cat
 
     def _can_prune(self) -> bool:
@@ -323,7 +321,7 @@ class LiteralKG(nn.Module):
             kept.append(norm if k == top else pruned.gather_rows(norm, sub.rows_in(top, k)))
         cat = torch.cat(kept, dim=1)
         if self.scale_gat_dim is not None:
-            cat = F.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias), ops.LEAKY_SLOPE)
+            cat = ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
         return cat, sub
 
     def _embeddings_and_ids(self, *id_lists):

@@ -224,6 +224,83 @@ def matmul(a, b):
     return _MatMul.apply(a, b)
 
 
+# ----------------------------------------------------------------------------- small element-wise steps
+def _elt(op, a, b=None, alpha=1.0, beta=0.0):
+    a = _f32_rows(a)
+    b = _f32_rows(b) if b is not None else None
+    if b is not None and b.shape != a.shape:
+        raise ValueError(f"element-wise operands differ in shape: {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    N.call("lkg_eltwise_f32", op, a.shape[0], a.shape[1], N.ptr(a), _ld(a), N.ptr(b), _ld(b) if b is not None else 0,
+           float(alpha), float(beta), N.ptr(out), _ld(out), _stream())
+    return out
+
+
+class _Axpby(Function):
+    """alpha * a + beta * b  (b None: alpha * a + beta)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        _need_gpu(a, b)
+        ctx.ab = (alpha, beta, b is not None)
+        return _elt(0, a, b, alpha, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta, has_b = ctx.ab
+        ga = _elt(0, g, None, alpha, 0.0) if ctx.needs_input_grad[0] else None
+        gb = _elt(0, g, None, beta, 0.0) if has_b and ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+def axpby(a, b, alpha=1.0, beta=1.0):
+    return _Axpby.apply(a, b, alpha, beta)
+
+
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        ctx.save_for_backward(a, b)
+        return _elt(1, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (_elt(1, g, b) if ctx.needs_input_grad[0] else None,
+                _elt(1, g, a) if ctx.needs_input_grad[1] else None)
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+class _LeakySum(Function):
+    """leaky_relu(a) + leaky_relu(b)  (b None: leaky_relu(a))."""
+
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        _need_gpu(a, b)
+        ctx.save_for_backward(a, b) if b is not None else ctx.save_for_backward(a)
+        ctx.slope = slope
+        return _elt(2, a, b, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        ga = _elt(3, g, saved[0], ctx.slope) if ctx.needs_input_grad[0] else None
+        gb = _elt(3, g, saved[1], ctx.slope) if len(saved) > 1 and ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+def leaky_relu(a, slope=LEAKY_SLOPE):
+    return _LeakySum.apply(a, None, slope)
+
+
+def leaky_relu_sum(a, b, slope=LEAKY_SLOPE):
+    return _LeakySum.apply(a, b, slope)
+
+
 # ----------------------------------------------------------------------------- K5 epilogue
 class _ActLayerNorm(Function):
     """y = Dropout(LayerNorm(LeakyReLU(z))); yn = y / max(|y|_2, eps)  (model.py:111, 161, 305).
