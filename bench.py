@@ -311,6 +311,22 @@ def main():
     elapsed = float(el)
     total_entries = int(nnz_all)
 
+    # feature mode: the same loop without the layout exchange (the SpMM hot path alone, which needs no collective),
+    # reported next to `value` so that the cost of the exchange is visible; not part of the timed region above
+    agg_only_ms = None
+    if mode == "features":
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fs.forward(slab, out=side_slab)
+            fs.backward(grad_slab, out=grad_table)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ao = torch.tensor([time.perf_counter() - t1], dtype=torch.float64).to(cdev)
+        dist.all_reduce(ao, op=dist.ReduceOp.MAX)
+        agg_only_ms = float(ao) / args.steps * 1e3
+
     # dominant kernel = the forward SpMM launch; HIP events on the launch stream (torch's current stream)
     fwd_ms = np.array([ev[0].elapsed_time(ev[1]) for ev in events])
     bwd_ms = np.array([ev[-2].elapsed_time(ev[-1]) for ev in events])
@@ -343,6 +359,8 @@ def main():
                 "skew": args.skew,
                 "host_graph_build_s": round(t_build, 2),
                 "spot_check": "ok" if float(valid) == 1.0 else "MISMATCH: 8 output rows per rank differ from a direct evaluation",
+                "spmm_only_ms_per_step": agg_only_ms,
+                "spmm_only_edges_per_s": (2 * total_entries / agg_only_ms * 1e3) if agg_only_ms else None,
             },
             "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel (forward launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
