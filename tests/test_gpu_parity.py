@@ -51,7 +51,7 @@ def coo_of(graph, val):
 
 
 # ----------------------------------------------------------------------------- K3/K4 SpMM
-@pytest.mark.parametrize("d", [4, 8, 30, 32, 64, 100, 128, 256, 300, 512, 1028])
+@pytest.mark.parametrize("d", [1, 4, 5, 7, 8, 16, 20, 30, 32, 64, 100, 128, 256, 300, 512, 1028])
 def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
     rng = np.random.default_rng(d)
     n = 700
@@ -72,6 +72,40 @@ def test_spmm_matches_oracle(L, ops, O, gpu_device, d):
     # transpose pass == A^T @ grad
     gt = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), x, n)
     torch.testing.assert_close(gt.cpu(), torch.matmul(coo_of(g, val).t(), x.cpu()), rtol=1e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("d", [12, 32, 48, 256])
+def test_spmm_self_add_row_ranges_and_offsets(L, ops, O, gpu_device, d):
+    """The forms the layers and the sharded paths use: out = self + A @ x, a row sub-range through a rowptr view
+    (with its own long-row list), and a source table handed over as a row block with x_row_offset."""
+    rng = np.random.default_rng(100 + d)
+    n = 900
+    h, t, r = rand_graph(rng, n, 9000, long_rows=[(7, 300), (450, 700), (899, 1)])
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    val = torch.rand(g.nnz, device=gpu_device)
+    x = torch.randn(n, d, device=gpu_device)
+    own = torch.randn(n, d, device=gpu_device)
+    full = O.aggregate(coo_of(g, val), x.cpu())
+    got = ops.spmm_raw(g.rowptr, g.col, val, x, n, long_rows=g.long_rows(False), add_self=own)
+    torch.testing.assert_close(got.cpu(), full + own.cpu(), rtol=1e-5, atol=5e-5)
+    # in place: out = out + A @ x
+    acc = own.clone()
+    ops.spmm_raw(g.rowptr, g.col, val, x, n, out=acc, long_rows=g.long_rows(False), add_self=acc)
+    torch.testing.assert_close(acc.cpu(), full + own.cpu(), rtol=1e-5, atol=5e-5)
+    for lo, hi in ((0, 13), (5, 460), (449, 451), (600, 900), (123, 123)):
+        part = ops.spmm_raw(g.rowptr[lo:hi + 1], g.col, val, x, hi - lo, long_rows=g.long_rows(False, lo, hi))
+        torch.testing.assert_close(part.cpu(), full[lo:hi], rtol=1e-5, atol=5e-5)
+    # transpose pass restricted to the heads [lo, hi): the source is only that row block (ShardedAggregation)
+    lo, hi = 200, 640
+    keep = (h >= lo) & (h < hi)
+    gs = L.KGStructure.from_triples(n, h[keep], t[keep], r[keep], device=gpu_device)
+    vs = torch.rand(gs.nnz, device=gpu_device)
+    grad_rows = torch.randn(hi - lo, d, device=gpu_device)
+    got_t = ops.spmm_raw(gs.t_rowptr, gs.t_col, ops.permute_values(vs, gs.t_perm), grad_rows, n, x_row_offset=lo,
+                         long_rows=gs.long_rows(True))
+    padded = torch.zeros(n, d)
+    padded[lo:hi] = grad_rows.cpu()
+    torch.testing.assert_close(got_t.cpu(), torch.matmul(coo_of(gs, vs).t(), padded), rtol=1e-5, atol=5e-5)
 
 
 def test_spmm_strided_views_and_autograd(L, ops, O, gpu_device):
