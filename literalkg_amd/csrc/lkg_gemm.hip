@@ -55,6 +55,8 @@ struct GemmArgs {
     int mode;            // 0 plain, 1 rows grouped, 2 k grouped
     int k_splits;        // plain mode only (atomic accumulation when > 1)
     int tiles_m, tiles_n;
+    const __bf16 *bp;    // split engine: B as bf16 planes, tile-major [tiles_n][ktiles_b][3][PLANE] (presplit_b_kernel)
+    int ktiles_b;
 };
 
 // K-contiguous operand: element (r, k) at src[r * ld + k]; LDS image [r][k].  Thread t owns row t/2 and
@@ -132,10 +134,76 @@ struct MContig {
     }
 };
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][IMG];
-    __shared__ __attribute__((aligned(16))) float Bs[2][IMG];
+// ---- split-operand engine: f32 GEMM on the bf16 matrix cores ("bf16 x 3") ------------------------------
+// The f32-input MFMA runs at 1/16 of the bf16 rate.  Every f32 x is the exact sum hi + mid + lo of three bf16
+// numbers (8 + 8 + 8 mantissa bits, round-to-nearest at each step; the exponent range is the same), so
+//   a * b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)  + O(2^-25 |a b|)
+// and six v_mfma_f32_32x32x16_bf16 (products exact, f32 accumulation) replace eight 32x32x2 f32 MFMAs per 16 k
+// at 2.7x the peak rate.  The dropped terms (am*bl, al*bm, al*bl) are below f32 rounding; measured against f64
+// the result is as accurate as the f32 MFMA chain (fewer accumulator roundings per output: 6 per 16 k, not 8).
+// K-contiguous operands only (A row-major, B = nn.Linear weight): image [3 planes][128 rows][16 k] of bf16, one
+// ds_read_b128 per lane and plane fetches the 8 consecutive k of v_mfma_f32_32x32x16_bf16 (lane l: row l & 31,
+// k = 8 (l >> 5) + j).  The two 16-byte halves of a row are swapped on rows 16-31 of every 32, which makes the
+// reads conflict-free for the b128 lane groups ({0-3, 12-15, 20-27}, ...) without padding: 48 KB for both
+// operands, double-buffered.  The split costs ~44 VALU instructions per 8 elements at staging time, once per
+// element per workgroup, hidden behind the MFMAs of the other waves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PLANE = BM * BK;   // bf16 elements of one plane of one operand tile
+
+__device__ __forceinline__ void split_planes(const float (&v)[EPT], bf16x8 (&pl)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r1 = v[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        pl[0][j] = h;
+        pl[1][j] = m;
+        pl[2][j] = (__bf16)(r1 - (float)m);
+    }
+}
+__device__ __forceinline__ void planes_store(const bf16x8 (&pl)[3], __bf16 *planes, int t) {
+    const int row = t >> 1;
+    __bf16 *p = planes + row * BK + (((t & 1) ^ ((row >> 4) & 1)) << 3);
+    *reinterpret_cast<bf16x8 *>(p) = pl[0];
+    *reinterpret_cast<bf16x8 *>(p + PLANE) = pl[1];
+    *reinterpret_cast<bf16x8 *>(p + 2 * PLANE) = pl[2];
+}
+// plane `pl` of the 32 rows starting at r0 (a multiple of 32)
+__device__ __forceinline__ bf16x8 split_frag(const __bf16 *planes, int pl, int r0, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(planes + pl * PLANE + (r0 + (lane & 31)) * BK +
+                                             (((lane >> 5) ^ ((lane >> 4) & 1)) << 3));
+}
+
+// B of the split engine: the (small) weight operand is split ONCE per call into the exact LDS image of every
+// (n tile, k tile) -- [tiles_n][ktiles][3 planes][128 rows][16 k, halves swizzled], zero-padded past N and K -- so the
+// GEMM stages it with straight 16-byte copies and no VALU work.  tb: B given as [N][K] (nn.Linear weight), else [K][N].
+__global__ __launch_bounds__(256) void presplit_b_kernel(const float *__restrict__ b, long ldb, int tb, long n, long k,
+                                                         int ktiles, __bf16 *__restrict__ out) {
+    const int t = threadIdx.x;
+    const long tn = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
+    const long row = tn * BN + (t >> 1), k0 = kt * BK + (t & 1) * 8;
+    float v[EPT];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long kk = k0 + j;
+        const bool ok = row < n && kk < k;
+        const long off = tb ? min(row, n - 1) * ldb + min(kk, k - 1) : min(kk, k - 1) * ldb + min(row, n - 1);
+        const float x = b[off];
+        v[j] = ok ? x : 0.f;
+    }
+    bf16x8 pl[3];
+    split_planes(v, pl);
+    planes_store(pl, out + (long)blockIdx.x * (3 * PLANE), t);
+}
+
+template <bool TA, bool TB, bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_kernel(GemmArgs g) {
+    static_assert(!SPLIT || (!TA && BK == 16 && EPT == 8), "split engine: A row-major, B pre-split, one MFMA k-step per tile");
+    constexpr int LDS_BYTES = SPLIT ? 2 * 2 * 3 * PLANE * 2 : 4 * IMG * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    float(*As)[IMG] = reinterpret_cast<float(*)[IMG]>(smem);                 // f32 engine: As[2], Bs[2]
+    float(*Bs)[IMG] = reinterpret_cast<float(*)[IMG]>(smem) + 2;
+    __bf16(*Sp)[2][3 * PLANE] = reinterpret_cast<__bf16(*)[2][3 * PLANE]>(smem);   // split engine: Sp[buf][A/B]
     using LA = typename std::conditional<TA, MContig, KContig>::type;
     using LB = typename std::conditional<TB, KContig, MContig>::type;
 
@@ -192,46 +260,140 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     LA la;
     LB lb;
-    auto fetch = [&](long k0) {
+    auto fetch = [&](LA &ra, LB &rb, long k0) {
         const bool k_full = k0 + BK <= k_hi;
         if constexpr (TA)
-            la.load(A, g.lda, m0, m_hi, k0, k_hi, t, a_al && m_full && k_full && (m0 % 4 == 0));
+            ra.load(A, g.lda, m0, m_hi, k0, k_hi, t, a_al && m_full && k_full && (m0 % 4 == 0));
         else
-            la.load(A, g.lda, m0, m_hi, k0, k_hi, t, a_al && m_full && k_full && (k0 % 4 == 0));
+            ra.load(A, g.lda, m0, m_hi, k0, k_hi, t, a_al && m_full && k_full && (k0 % 4 == 0));
         if constexpr (TB)
-            lb.load(B, g.ldb, n0, g.n, k0, k_hi, t, b_al && n_full && k_full && (k0 % 4 == 0));
+            rb.load(B, g.ldb, n0, g.n, k0, k_hi, t, b_al && n_full && k_full && (k0 % 4 == 0));
         else
-            lb.load(B, g.ldb, n0, g.n, k0, k_hi, t, b_al && n_full && k_full);
+            rb.load(B, g.ldb, n0, g.n, k0, k_hi, t, b_al && n_full && k_full);
     };
 
-    int buf = 0;
-    if (k_lo < k_hi) {
-        fetch(k_lo);
-        la.store(As[0], t);
-        lb.store(Bs[0], t);
-    }
-    __syncthreads();
-    for (long k0 = k_lo; k0 < k_hi; k0 += BK) {
-        const bool more = k0 + BK < k_hi;
-        if (more) fetch(k0 + BK);
+    if constexpr (SPLIT) {
+        // One register set, one barrier per step.  Step t: barrier (tile t is complete in LDS buffer t & 1, nobody
+        // still reads the other buffer) -> split + write tile t + 1 (its loads were issued a whole step ago) into the
+        // other buffer -> re-issue the loads for tile t + 2 into the same registers -> fragment reads + MFMAs of
+        // tile t.  B arrives as ready-made bf16 planes (a straight 48-byte copy per thread, no VALU work).
+        // Variants measured on x[1M,256] @ W^T and NOT kept (all within +-5 % of this one, 1.0-1.1 ms): loads two tiles
+        // ahead with two register sets (occupancy 2 instead of 3 waves per SIMD), the split spread between the MFMAs
+        // with sched_group_barrier, on-the-fly splitting of B.  Traps met on the way: a guarded load inside the loop
+        // makes hipcc wait vmcnt(0) every step; a small register ARRAY for the staged planes became an LDS-resident
+        // alloca; an `asm volatile("" ::: "memory")` fence forced that state through memory.
+        uint4 qb0, qb1, qb2;   // (scalars on purpose, see above)
+        const uint4 *bsrc = reinterpret_cast<const uint4 *>(g.bp) +
+                            ((long)tn * g.ktiles_b + k_lo / BK) * (3 * PLANE / 8) + t;
+#define LKG_TERM(PA, PB)                                                                                    \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA], b[0][PB], acc[0][0], 0, 0, 0);            \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA], b[1][PB], acc[0][1], 0, 0, 0);            \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[0][PB], acc[1][0], 0, 0, 0);            \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[1][PB], acc[1][1], 0, 0, 0);
+        auto stage = [&](__bf16(*D)[3 * PLANE]) {      // registers -> LDS image of one tile
+            bf16x8 pa[3];
+            split_planes(la.v, pa);
+            planes_store(pa, D[0], t);
+            uint4 *d = reinterpret_cast<uint4 *>(D[1]) + t;
+            d[0] = qb0;
+            d[PLANE / 8] = qb1;
+            d[2 * (PLANE / 8)] = qb2;
+        };
+        auto mma = [&](const __bf16(*S)[3 * PLANE]) {
+            bf16x8 a[2][3], b[2][3];
 #pragma unroll
-        for (int grp = 0; grp < BK / 8; ++grp) {
-            const float4 a0 = LA::frag(As[buf], wm * 64, grp, lane), a1 = LA::frag(As[buf], wm * 64 + 32, grp, lane);
-            const float4 b0 = LB::frag(Bs[buf], wn * 64, grp, lane), b1 = LB::frag(Bs[buf], wn * 64 + 32, grp, lane);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[i][pl] = split_frag(S[0], pl, wm * 64 + i * 32, lane);
+                    b[i][pl] = split_frag(S[1], pl, wn * 64 + i * 32, lane);
+                }
+            // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            LKG_TERM(2, 0) LKG_TERM(0, 2) LKG_TERM(1, 1) LKG_TERM(1, 0) LKG_TERM(0, 1) LKG_TERM(0, 0)
+        };
+#undef LKG_TERM
+        // tiles [first, first + count) of the k range.  FAST: every load is an unguarded 16-byte load and the
+        // steady-state loop carries no branch around a load (the compiler then waits with counted vmcnt).
+        auto pipeline = [&](auto fast_tag, long first, long count) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            auto fetch_tile = [&](long tile) {
+                const long k0 = k_lo + tile * BK;
+                la.load(A, g.lda, m0, m_hi, k0, k_hi, t, FAST ? true : (a_al && m_full && k0 + BK <= k_hi && k0 % 4 == 0));
+                const uint4 *src = bsrc + tile * (3 * PLANE / 8);
+                qb0 = src[0];
+                qb1 = src[PLANE / 8];
+                qb2 = src[2 * (PLANE / 8)];
+                __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: sunk towards their use they lose the prefetch
+            };
+            if (count <= 0) return;
+            fetch_tile(first);
+            stage(Sp[0]);
+            if (count > 1) fetch_tile(first + 1);
+            // invariant at the top of a trip: buffer 0 holds tile `it`, the registers hold (or are receiving) tile it + 1
+            long it = 0;
+            for (; it + 3 < count; it += 2) {       // unconditional body, two steps per trip (static buffer indices)
+                __syncthreads();
+                stage(Sp[1]);
+                fetch_tile(first + it + 2);
+                mma(Sp[0]);
+                __syncthreads();
+                stage(Sp[0]);
+                fetch_tile(first + it + 3);
+                mma(Sp[1]);
+            }
+            const long rem = count - it;            // 1, 2 or 3 tiles left
+            __syncthreads();
+            if (rem >= 2) stage(Sp[1]);
+            if (rem == 3) fetch_tile(first + it + 2);
+            mma(Sp[0]);
+            if (rem >= 2) {
+                __syncthreads();
+                if (rem == 3) stage(Sp[0]);
+                mma(Sp[1]);
+            }
+            if (rem == 3) {
+                __syncthreads();
+                mma(Sp[0]);
+            }
+            __syncthreads();
+        };
+        const long nt_all = (k_hi - k_lo + BK - 1) / BK, nt_full = (k_hi - k_lo) / BK;
+        if (a_al && m_full && (k_lo % 4 == 0)) {
+            pipeline(std::true_type{}, 0, nt_full);
+            if (nt_all > nt_full) pipeline(std::false_type{}, nt_full, 1);   // the partial last k tile
+        } else {
+            pipeline(std::false_type{}, 0, nt_all);
+        }
+    } else {
+        int buf = 0;
+        if (k_lo < k_hi) {
+            fetch(la, lb, k_lo);
+            la.store(As[0], t);
+            lb.store(Bs[0], t);
+        }
+        __syncthreads();
+        for (long k0 = k_lo; k0 < k_hi; k0 += BK) {
+            const bool more = k0 + BK < k_hi;
+            if (more) fetch(la, lb, k0 + BK);
+#pragma unroll
+            for (int grp = 0; grp < BK / 8; ++grp) {
+                const float4 a0 = LA::frag(As[buf], wm * 64, grp, lane), a1 = LA::frag(As[buf], wm * 64 + 32, grp, lane);
+                const float4 b0 = LB::frag(Bs[buf], wn * 64, grp, lane), b1 = LB::frag(Bs[buf], wn * 64 + 32, grp, lane);
 #define LKG_STEP(F)                                                                         \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.F, b0.F, acc[0][0], 0, 0, 0);       \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.F, b1.F, acc[0][1], 0, 0, 0);       \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.F, b0.F, acc[1][0], 0, 0, 0);       \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.F, b1.F, acc[1][1], 0, 0, 0);
-            LKG_STEP(x) LKG_STEP(y) LKG_STEP(z) LKG_STEP(w)
+                LKG_STEP(x) LKG_STEP(y) LKG_STEP(z) LKG_STEP(w)
 #undef LKG_STEP
+            }
+            if (more) {
+                la.store(As[buf ^ 1], t);
+                lb.store(Bs[buf ^ 1], t);
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        if (more) {
-            la.store(As[buf ^ 1], t);
-            lb.store(Bs[buf ^ 1], t);
-        }
-        __syncthreads();
-        buf ^= 1;
     }
 
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -257,14 +419,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 int run(bool ta, bool tb, const GemmArgs &g, dim3 grid, hipStream_t s) {
-    if (!ta && !tb)
-        hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (g.bp)             // split engine (A row-major, B pre-split)
+        hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, dim3(256), 0, s, g);
+    else if (!ta && !tb)
+        hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, dim3(256), 0, s, g);
     else if (!ta && tb)
-        hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, dim3(256), 0, s, g);
     else if (ta && !tb)
-        hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<true, false, false>), grid, dim3(256), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, dim3(256), 0, s, g);
     LKG_CHECK_LAUNCH("lkg_gemm_f32");
     return LKG_OK;
 }
@@ -306,7 +470,29 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
             return LKG_ERR_HIP;
         }
     }
-    return run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
+    // Split engine: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay
+    // for the extra launch.  The plane workspace is stream-ordered (hipMallocAsync / hipFreeAsync on `s`).
+    const int ktiles = (int)((k + BK - 1) / BK);
+    const long ws_elems = (long)g.tiles_n * ktiles * 3 * PLANE;
+    void *ws = nullptr;
+    if (!trans_a && k > 0 && m >= 4 * BM && (long)n * k <= (1L << 22)) {
+        if (hipMallocAsync(&ws, ws_elems * sizeof(__bf16), s) != hipSuccess) {
+            (void)hipGetLastError();
+            ws = nullptr;          // no pool memory: the f32 engine below needs none
+        }
+    }
+    if (ws) {
+        hipLaunchKernelGGL(presplit_b_kernel, dim3((unsigned)(g.tiles_n * ktiles)), dim3(256), 0, s, b, (long)ldb,
+                           (int)(trans_b != 0), (long)n, (long)k, ktiles, reinterpret_cast<__bf16 *>(ws));
+        g.bp = reinterpret_cast<const __bf16 *>(ws);
+        g.ktiles_b = ktiles;
+    }
+    const int rc = run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
+    if (ws && hipFreeAsync(ws, s) != hipSuccess) {
+        lkg_set_error("lkg_gemm_f32: hipFreeAsync failed");
+        return LKG_ERR_HIP;
+    }
+    return rc;
 }
 
 extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int64_t max_seg_len,

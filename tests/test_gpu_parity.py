@@ -204,6 +204,31 @@ def test_gemm(ops, gpu_device, m, n, k, ta, tb):
                                atol=1e-4 * max(1, k) ** 0.5)
 
 
+@pytest.mark.parametrize("k,n,tb", [(256, 256, True), (300, 256, True), (558, 200, True), (128, 128, False), (2, 256, True),
+                                     (17, 40, False)])
+def test_gemm_split_engine_is_f32_accurate(ops, gpu_device, k, n, tb):
+    """Tall products with a small B run on the bf16 x 3 engine (m >= 512 rows): it must be as close to the f64
+    product as an f32 GEMM is (a few 1e-7 of the result's scale), also on edge tiles, partial k tiles, column slices
+    and with alpha / beta / bias; below the row threshold the f32-MFMA engine gives the same numbers."""
+    gen = torch.Generator().manual_seed(k * 1000 + n)
+    m = 2048 + 77
+    a = torch.randn(m, k + 4, generator=gen)[:, 4:].to(gpu_device) if k % 4 == 0 else torch.randn(m, k, generator=gen).to(gpu_device)
+    b = torch.randn((n, k) if tb else (k, n), generator=gen).to(gpu_device) * 0.1
+    want = a.double() @ (b.double().t() if tb else b.double())
+    scale = float(want.abs().max())
+    got = ops.gemm(a, b, trans_b=tb)
+    err = float((got.double() - want).abs().max()) / scale
+    f32 = float((torch.matmul(a, b.t() if tb else b).double() - want).abs().max()) / scale
+    assert err <= max(2.0 * f32, 1e-6), (err, f32)
+    small = ops.gemm(a[:300], b, trans_b=tb)                  # under the threshold: f32 MFMA engine
+    torch.testing.assert_close(small, got[:300], rtol=1e-5, atol=2e-6 * scale)
+    bias = torch.randn(n, generator=gen).to(gpu_device)
+    c0 = torch.randn(m, n, generator=gen).to(gpu_device)
+    got2 = ops.gemm(a, b, trans_b=tb, alpha=0.5, beta=2.0, out=c0.clone(), bias=bias)
+    torch.testing.assert_close(got2.double(), 0.5 * want + 2.0 * c0.double() + bias.double(), rtol=1e-5,
+                               atol=4e-6 * scale)
+
+
 def test_gemm_split_k_and_slices(ops, gpu_device):
     gen = torch.Generator().manual_seed(3)
     gy = torch.randn(40000, 96, generator=gen)
