@@ -32,20 +32,56 @@ static inline bool lkg_aligned16(const void *p) { return (reinterpret_cast<uintp
 
 #ifdef __HIPCC__
 // ---- wave64 cross-lane reductions -------------------------------------------------
-// Sum over aligned groups of WIDTH lanes (WIDTH a power of two <= 64); every lane of a
-// group ends with the group's total.
-template <int WIDTH>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Reduction over aligned groups of WIDTH lanes (WIDTH a power of two <= 64); every lane of a group ends with the
+// group's total.  The butterfly runs on the VALU: DPP lane permutes inside a row of 16 (they fuse into the add /
+// max itself), v_permlane16_swap / v_permlane32_swap (gfx950) across rows -- HIP's __shfl_xor is a ds_bpermute,
+// an LDS-pipeline round trip per step.  Bit-identical to the xor butterfly (after steps 1 and 2 the lanes of a quad
+// hold the same bits, so the mirror permutes deliver what lane ^ 4 / lane ^ 8 would).  Call with all lanes active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+struct lkg_sum_op {
+    static __device__ __forceinline__ float apply(float a, float b) { return a + b; }
+};
+struct lkg_max_op {
+    static __device__ __forceinline__ float apply(float a, float b) { return fmaxf(a, b); }
+};
+template <int WIDTH, typename OP>
+__device__ __forceinline__ float group_reduce(float v) {
+    static_assert(WIDTH >= 1 && WIDTH <= 64 && (WIDTH & (WIDTH - 1)) == 0, "group width");
+    if constexpr (WIDTH >= 2) v = OP::apply(v, dpp_read<0xB1>(v));    // quad_perm [1,0,3,2]: lane ^ 1
+    if constexpr (WIDTH >= 4) v = OP::apply(v, dpp_read<0x4E>(v));    // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (WIDTH >= 8) v = OP::apply(v, dpp_read<0x141>(v));   // row_half_mirror: the other quad of 8
+    if constexpr (WIDTH >= 16) v = OP::apply(v, dpp_read<0x140>(v));  // row_mirror: the other half of 16
+    if constexpr (WIDTH >= 32) {   // rows 1,3 of the first copy <-> rows 0,2 of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+        v = OP::apply(__int_as_float(r[0]), __int_as_float(r[1]));
+    }
+    if constexpr (WIDTH >= 64) {   // lanes 32-63 of the first copy <-> lanes 0-31 of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        v = OP::apply(__int_as_float(r[0]), __int_as_float(r[1]));
+    }
     return v;
 }
-template <int WIDTH>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+// v + (v of lane ^ M) for one butterfly step, M in {8, 16, 32} (the steps ABOVE a sub-group of 8+ lanes)
+template <int M>
+__device__ __forceinline__ float lane_xor_add(float v) {
+    static_assert(M == 8 || M == 16 || M == 32, "lane_xor_add: step");
+    if constexpr (M == 8) {
+        return v + dpp_read<0x128>(v);    // row_ror:8 inside a row of 16 == lane ^ 8
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+        return __int_as_float(r[0]) + __int_as_float(r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        return __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
 }
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) { return group_reduce<WIDTH, lkg_sum_op>(v); }
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) { return group_reduce<WIDTH, lkg_max_op>(v); }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 

@@ -26,10 +26,10 @@ struct vec_ops<float4> {
     static __device__ __forceinline__ void fma(float4 &a, float s, const float4 &x) { f4_fma(a, s, x); }
     template <int M>
     static __device__ __forceinline__ void xor_add(float4 &a) {
-        a.x += __shfl_xor(a.x, M, 64);
-        a.y += __shfl_xor(a.y, M, 64);
-        a.z += __shfl_xor(a.z, M, 64);
-        a.w += __shfl_xor(a.w, M, 64);
+        a.x = lane_xor_add<M>(a.x);
+        a.y = lane_xor_add<M>(a.y);
+        a.z = lane_xor_add<M>(a.z);
+        a.w = lane_xor_add<M>(a.w);
     }
 };
 template <>
@@ -38,7 +38,7 @@ struct vec_ops<float> {
     static __device__ __forceinline__ float zero() { return 0.f; }
     static __device__ __forceinline__ void fma(float &a, float s, const float &x) { a = fmaf(s, x, a); }
     template <int M>
-    static __device__ __forceinline__ void xor_add(float &a) { a += __shfl_xor(a, M, 64); }
+    static __device__ __forceinline__ void xor_add(float &a) { a = lane_xor_add<M>(a); }
 };
 
 template <typename V, int LPE>
