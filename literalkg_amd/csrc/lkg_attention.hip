@@ -130,8 +130,13 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idc = min(k + u * EPW + sub, last);
-                cc[u] = __shfl(c, idc, 64);
-                rr[u] = __shfl(r0, idc, 64);
+                if constexpr (LPE == 64) {   // one entry per wave step: the index is wave-uniform, scalar broadcast
+                    cc[u] = __builtin_amdgcn_readlane(c, idc);
+                    rr[u] = __builtin_amdgcn_readlane(r0, idc);
+                } else {
+                    cc[u] = __shfl(c, idc, 64);
+                    rr[u] = __shfl(r0, idc, 64);
+                }
             }
             V tv[U][CPL], rv[U][CPL];
 #pragma unroll
@@ -149,18 +154,28 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
             for (int u = 0; u < U; ++u) {
                 float p = 0.f;
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) p += live[i] ? ops::tanh_dot(tv[u][i], hv[i], rv[u][i]) : 0.f;
+                for (int i = 0; i < CPL; ++i) {
+                    // all lanes evaluate (tanh_dot holds a wave-wide ballot: under a lane predicate it would turn into
+                    // an exec-masked branch per entry); lanes past the row end hold clamped copies and are dropped here
+                    const float q = ops::tanh_dot(tv[u][i], hv[i], rv[u][i]);
+                    p += live[i] ? q : 0.f;
+                }
                 part[u] = p;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = k + u * EPW + sub;
                 float tot = group_sum<LPE>(part[u]);
-                if constexpr (DUPS) tot += __shfl(pre, min(idx, last), 64);
+                if constexpr (DUPS) {
+                    if constexpr (LPE == 64)
+                        tot += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre), min(idx, last)));
+                    else
+                        tot += __shfl(pre, min(idx, last), 64);
+                }
                 if (in_regs) {
                     // entry e = k + u*EPW + s was summed by sub-group s: lane e fetches it from that group's lane 0
                     const int rel_e = lane - (k + u * EPW);
-                    const float mine = __shfl(tot, (rel_e & (EPW - 1)) * LPE, 64);
+                    const float mine = (EPW == 1) ? tot : __shfl(tot, (rel_e & (EPW - 1)) * LPE, 64);
                     if (rel_e >= 0 && rel_e < EPW) mylogit = mine;
                     if (logits_out && sl == 0 && idx < cnt) logits_out[base + idx] = tot;
                 } else if (sl == 0 && idx < cnt) {
@@ -255,7 +270,10 @@ int dispatch(const EsArgs &a, hipStream_t s) {
     if (nchunk <= 8) return launch<V, 8, 1, 2>(a, s);
     if (nchunk <= 16) return launch<V, 16, 1, 2>(a, s);
     if (nchunk <= 32) return launch<V, 32, 1, 2>(a, s);
-    if (nchunk <= 64) return launch<V, 64, 1, 2>(a, s);
+#ifndef LKG_ATT_U64
+#define LKG_ATT_U64 2
+#endif
+    if (nchunk <= 64) return launch<V, 64, 1, LKG_ATT_U64>(a, s);
     if (nchunk <= 128) return launch<V, 64, 2, 2>(a, s);
     if (nchunk <= 192) return launch<V, 64, 3, 2>(a, s);
     if (nchunk <= 256) return launch<V, 64, 4, 1>(a, s);

@@ -32,7 +32,7 @@ print(f"act_ln bwd (gy + gyn)          {t:.3f} ms  {5*gb/t*1e3:.0f} GB/s")
 t = timeit(lambda: ops.colsum(z))
 print(f"colsum                         {t:.3f} ms  {gb/t*1e3:.0f} GB/s")
 x = torch.randn(n, d, device=dev); gp = torch.randn(n, d, device=dev); zp = torch.randn(n, d, device=dev)
-t = timeit(lambda: ops._GateBlend.apply(x, gp, zp))
+t = timeit(lambda: ops._GateBlend.apply(x, gp, zp, None))
 print(f"gate blend fwd                 {t:.3f} ms  {4*gb/t*1e3:.0f} GB/s")
 xg = x.clone().requires_grad_(True); gpg = gp.clone().requires_grad_(True); zpg = zp.clone().requires_grad_(True)
 o = ops.gate_blend(xg, gpg, zpg)
