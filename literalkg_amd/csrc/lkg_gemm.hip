@@ -258,6 +258,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float bias_v[2] = {0.f, 0.f};       // this lane's two output columns; fetched now, long complete at the epilogue
+    if (g.bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long col = n0 + wn * 64 + j * 32 + (lane & 31);
+            bias_v[j] = g.bias[min(col, g.n - 1)];
+        }
+    }
+
     LA la;
     LB lb;
     auto fetch = [&](LA &ra, LB &rb, long k0) {
@@ -396,24 +405,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
 
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // The 16 stores of a tile are issued back to back, all reads they need (bias: fetched before the k loop; old C for
+    // beta != 0: the tile's 16 loads first) done beforehand: stores count in vmcnt on gfx9, so a load pending anywhere
+    // between them made hipcc drain with vmcnt(0) before EVERY store -- 64 serialised write round trips per thread,
+    // 42 of the 81 k-cycles of a workgroup on x[1M,256] @ W^T.
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const long col = n0 + wn * 64 + j * 32 + (lane & 31);
             if (col >= g.n) continue;
-            const float bv = (g.bias && (!atomic_out || z == 0)) ? g.bias[col] : 0.f;
+            const float bv = (!atomic_out || z == 0) ? bias_v[j] : 0.f;
+            const long row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            float *dst0 = C + row0 * g.ldc + col;
+            const bool all_rows = m0 + wm * 64 + i * 32 + 32 <= m_hi;      // wave-uniform
+            float out[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= m_hi) continue;
-                float *dst = C + row * g.ldc + col;
-                const float val = g.alpha * acc[i][j][r] + bv;
-                if (atomic_out)
-                    atomicAdd(dst, val);
-                else
-                    *dst = (g.beta != 0.f) ? fmaf(g.beta, *dst, val) : val;
+            for (int r = 0; r < 16; ++r) out[r] = g.alpha * acc[i][j][r] + bv;
+            if (atomic_out) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (all_rows || row0 + dr < m_hi) atomicAdd(dst0 + dr * g.ldc, out[r]);
+                }
+            } else {
+                if (g.beta != 0.f) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        old[r] = (all_rows || row0 + dr < m_hi) ? dst0[dr * g.ldc] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[r] = fmaf(g.beta, old[r], out[r]);
+                }
+                if (all_rows) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst0[((r & 3) + 8 * (r >> 2)) * g.ldc] = out[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (row0 + dr < m_hi) dst0[dr * g.ldc] = out[r];
+                    }
+                }
             }
         }
 }
