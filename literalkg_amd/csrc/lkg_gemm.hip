@@ -57,6 +57,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     const __bf16 *bp;    // split engine: B as bf16 planes, tile-major [tiles_n][ktiles_b][3][PLANE] (presplit_b_kernel)
     int ktiles_b;
+    int split_km;        // split engine 2: both operands k-major, split on the fly
 };
 
 // K-contiguous operand: element (r, k) at src[r * ld + k]; LDS image [r][k].  Thread t owns row t/2 and
@@ -174,6 +175,37 @@ __device__ __forceinline__ bf16x8 split_frag(const __bf16 *planes, int pl, int r
                                              (((lane >> 5) ^ ((lane >> 4) & 1)) << 3));
 }
 
+// ---- k-major operands (A given transposed, B row-major: the weight gradient  dW = dY^T X, k = rows) ------
+// Image per plane [16 k][128 cols] bf16, 256-byte rows, written as it arrives (a thread owns 8 consecutive columns of
+// one k).  The MFMA wants 8 consecutive k of ONE column per lane: ds_read_b64_tr_b16 (gfx950) reads, per 16 lanes, a
+// 4-row x 16-column block and hands every lane one column of it -- two of them make the fragment, no transpose pass.
+// Lane 4q + p of a 16-lane group supplies the address of row q, columns 4p .. 4p+3 of its block; lane i receives
+// column i.  The 64-byte chunk index of a row is XORed with (k & 3): the four rows of a block then sit in different
+// banks (256-byte rows would otherwise put them on the same 16), reads and the 16-byte writes are conflict-free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int kmajor_off(int k, int c) {   // element offset of (k, c) inside a plane
+    return k * BM + ((((c >> 5) ^ (k & 3)) << 5) | (c & 31));
+}
+__device__ __forceinline__ void kmajor_store(const bf16x8 (&pl)[3], __bf16 *planes, int t) {
+    __bf16 *p = planes + kmajor_off(t >> 4, (t & 15) * 8);
+    *reinterpret_cast<bf16x8 *>(p) = pl[0];
+    *reinterpret_cast<bf16x8 *>(p + PLANE) = pl[1];
+    *reinterpret_cast<bf16x8 *>(p + 2 * PLANE) = pl[2];
+}
+// plane `pl`, the 32 columns starting at c0 (a multiple of 32): this lane's column c0 + (lane & 31), k = 8 (lane >> 5) ..
+__device__ __forceinline__ bf16x8 kmajor_frag(const __bf16 *planes, int pl, int c0, int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int col = c0 + (lane & 16) + 4 * pp;
+    const int k0 = 8 * (lane >> 5) + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const __bf16 *base = planes + pl * PLANE;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(base + kmajor_off(k0, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(base + kmajor_off(k0 + 4, col)));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
 // B of the split engine: the (small) weight operand is split ONCE per call into the exact LDS image of every
 // (n tile, k tile) -- [tiles_n][ktiles][3 planes][128 rows][16 k, halves swizzled], zero-padded past N and K -- so the
 // GEMM stages it with straight 16-byte copies and no VALU work.  tb: B given as [N][K] (nn.Linear weight), else [K][N].
@@ -196,10 +228,11 @@ __global__ __launch_bounds__(256) void presplit_b_kernel(const float *__restrict
     planes_store(pl, out + (long)blockIdx.x * (3 * PLANE), t);
 }
 
-template <bool TA, bool TB, bool SPLIT>
+template <bool TA, bool TB, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_kernel(GemmArgs g) {
-    static_assert(!SPLIT || (!TA && BK == 16 && EPT == 8), "split engine: A row-major, B pre-split, one MFMA k-step per tile");
-    constexpr int LDS_BYTES = SPLIT ? 2 * 2 * 3 * PLANE * 2 : 4 * IMG * 4;
+    static_assert(SPLIT == 0 || (BK == 16 && EPT == 8 && (SPLIT == 1 ? !TA : (TA && !TB))),
+                  "split engines: 1 = A row-major + pre-split B, 2 = both operands k-major (weight gradient)");
+    constexpr int LDS_BYTES = SPLIT != 0 ? 2 * 2 * 3 * PLANE * 2 : 4 * IMG * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     float(*As)[IMG] = reinterpret_cast<float(*)[IMG]>(smem);                 // f32 engine: As[2], Bs[2]
     float(*Bs)[IMG] = reinterpret_cast<float(*)[IMG]>(smem) + 2;
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             rb.load(B, g.ldb, n0, g.n, k0, k_hi, t, b_al && n_full && k_full);
     };
 
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 1) {
         // One register set, one barrier per step.  Step t: barrier (tile t is complete in LDS buffer t & 1, nobody
         // still reads the other buffer) -> split + write tile t + 1 (its loads were issued a whole step ago) into the
         // other buffer -> re-issue the loads for tile t + 2 into the same registers -> fragment reads + MFMAs of
@@ -373,6 +406,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         } else {
             pipeline(std::false_type{}, 0, nt_all);
         }
+    } else if constexpr (SPLIT == 2) {
+        // Both operands k-major and large (weight gradient): the same one-register-set pipeline, both operands split
+        // on the fly (about 88 VALU per thread and step), fragments by transposing LDS reads (kmajor_frag).
+#define LKG_TERM(PA, PB)                                                                                    \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA], b[0][PB], acc[0][0], 0, 0, 0);            \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA], b[1][PB], acc[0][1], 0, 0, 0);            \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[0][PB], acc[1][0], 0, 0, 0);            \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[1][PB], acc[1][1], 0, 0, 0);
+        auto stage = [&](__bf16(*D)[3 * PLANE]) {
+            bf16x8 pa[3], pb[3];
+            split_planes(la.v, pa);
+            split_planes(lb.v, pb);
+            kmajor_store(pa, D[0], t);
+            kmajor_store(pb, D[1], t);
+        };
+        auto mma = [&](const __bf16(*S)[3 * PLANE]) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[i][pl] = kmajor_frag(S[0], pl, wm * 64 + i * 32, lane);
+                    b[i][pl] = kmajor_frag(S[1], pl, wn * 64 + i * 32, lane);
+                }
+            LKG_TERM(2, 0) LKG_TERM(0, 2) LKG_TERM(1, 1) LKG_TERM(1, 0) LKG_TERM(0, 1) LKG_TERM(0, 0)
+        };
+#undef LKG_TERM
+        auto pipeline = [&](auto fast_tag, long first, long count) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            auto fetch_tile = [&](long tile) {
+                const long k0 = k_lo + tile * BK;
+                if constexpr (FAST) {
+                    la.load(A, g.lda, m0, m_hi, k0, k_hi, t, true);
+                    lb.load(B, g.ldb, n0, g.n, k0, k_hi, t, true);
+                } else {
+                    fetch(la, lb, k0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (count <= 0) return;
+            fetch_tile(first);
+            stage(Sp[0]);
+            if (count > 1) fetch_tile(first + 1);
+            long it = 0;
+            for (; it + 3 < count; it += 2) {
+                __syncthreads();
+                stage(Sp[1]);
+                fetch_tile(first + it + 2);
+                mma(Sp[0]);
+                __syncthreads();
+                stage(Sp[0]);
+                fetch_tile(first + it + 3);
+                mma(Sp[1]);
+            }
+            const long rem = count - it;
+            __syncthreads();
+            if (rem >= 2) stage(Sp[1]);
+            if (rem == 3) fetch_tile(first + it + 2);
+            mma(Sp[0]);
+            if (rem >= 2) {
+                __syncthreads();
+                if (rem == 3) stage(Sp[0]);
+                mma(Sp[1]);
+            }
+            if (rem == 3) {
+                __syncthreads();
+                mma(Sp[0]);
+            }
+            __syncthreads();
+        };
+        const long nt_all = (k_hi - k_lo + BK - 1) / BK, nt_full = (k_hi - k_lo) / BK;
+        if (a_al && b_al && m_full && n_full && (m0 % 4 == 0)) {
+            pipeline(std::true_type{}, 0, nt_full);
+            if (nt_all > nt_full) pipeline(std::false_type{}, nt_full, 1);
+        } else {
+            pipeline(std::false_type{}, 0, nt_all);
+        }
     } else {
         int buf = 0;
         if (k_lo < k_hi) {
@@ -455,16 +565,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 int run(bool ta, bool tb, const GemmArgs &g, dim3 grid, hipStream_t s) {
-    if (g.bp)             // split engine (A row-major, B pre-split)
-        hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, dim3(256), 0, s, g);
+    if (g.bp)             // split engine 1 (A row-major, B pre-split)
+        hipLaunchKernelGGL((gemm_kernel<false, true, 1>), grid, dim3(256), 0, s, g);
+    else if (g.split_km)  // split engine 2 (both operands k-major)
+        hipLaunchKernelGGL((gemm_kernel<true, false, 2>), grid, dim3(256), 0, s, g);
     else if (!ta && !tb)
-        hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<false, false, 0>), grid, dim3(256), 0, s, g);
     else if (!ta && tb)
-        hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<false, true, 0>), grid, dim3(256), 0, s, g);
     else if (ta && !tb)
-        hipLaunchKernelGGL((gemm_kernel<true, false, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<true, false, 0>), grid, dim3(256), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<true, true, 0>), grid, dim3(256), 0, s, g);
     LKG_CHECK_LAUNCH("lkg_gemm_f32");
     return LKG_OK;
 }
@@ -523,6 +635,7 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
         g.bp = reinterpret_cast<const __bf16 *>(ws);
         g.ktiles_b = ktiles;
     }
+    g.split_km = (trans_a && !trans_b && k >= 2048) ? 1 : 0;   // long reductions over rows: weight gradients
     const int rc = run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
     if (ws && hipFreeAsync(ws, s) != hipSuccess) {
         lkg_set_error("lkg_gemm_f32: hipFreeAsync failed");

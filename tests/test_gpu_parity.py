@@ -229,6 +229,25 @@ def test_gemm_split_engine_is_f32_accurate(ops, gpu_device, k, n, tb):
                                atol=4e-6 * scale)
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 30000), (96, 300, 5000), (130, 70, 2048), (256, 128, 4099)])
+def test_gemm_weight_gradient_engine_is_f32_accurate(ops, gpu_device, m, n, k):
+    """A^T B with both operands k-major and k >= 2048 (nn.Linear weight gradients) runs on the second bf16 x 3 engine
+    (transposing LDS reads, split-K atomics): as close to f64 as torch's f32 result, edge tiles and partial k tiles
+    included; below the k threshold the f32-MFMA engine gives the same numbers."""
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(k, m, generator=gen).to(gpu_device)
+    b = torch.randn(k, n, generator=gen).to(gpu_device)
+    want = a.double().t() @ b.double()
+    scale = float(want.abs().max())
+    got = ops.gemm(a, b, trans_a=True)
+    err = float((got.double() - want).abs().max()) / scale
+    f32 = float((torch.matmul(a.t(), b).double() - want).abs().max()) / scale
+    assert err <= max(2.0 * f32, 2e-6), (err, f32)
+    head = ops.gemm(a[:2000], b[:2000], trans_a=True)          # k < 2048: f32 MFMA engine
+    want_head = a[:2000].double().t() @ b[:2000].double()
+    torch.testing.assert_close(head.double(), want_head, rtol=1e-5, atol=2e-6 * float(want_head.abs().max()))
+
+
 def test_gemm_split_k_and_slices(ops, gpu_device):
     gen = torch.Generator().manual_seed(3)
     gy = torch.randn(40000, 96, generator=gen)
