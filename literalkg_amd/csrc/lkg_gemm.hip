@@ -618,12 +618,23 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
             return LKG_ERR_HIP;
         }
     }
-    // Split engine: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay
+    // Split engine 1: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay
     // for the extra launch.  The plane workspace is stream-ordered (hipMallocAsync / hipFreeAsync on `s`).
     const int ktiles = (int)((k + BK - 1) / BK);
     const long ws_elems = (long)g.tiles_n * ktiles * 3 * PLANE;
     void *ws = nullptr;
-    if (!trans_a && k > 0 && m >= 4 * BM && (long)n * k <= (1L << 22)) {
+    // (below ~16 k rows the call is bound by its host-side issue, ~12 us; workspace + pre-split add ~11 us of that)
+    if (!trans_a && k > 0 && m >= 16384 && (long)n * k <= (1L << 22)) {
+        static bool pool_ready = false;     // keep freed workspaces in the pool instead of returning them at every sync
+        if (!pool_ready) {
+            int dev = 0;
+            hipMemPool_t pool;
+            uint64_t keep = UINT64_MAX;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            (void)hipGetLastError();
+            pool_ready = true;
+        }
         if (hipMallocAsync(&ws, ws_elems * sizeof(__bf16), s) != hipSuccess) {
             (void)hipGetLastError();
             ws = nullptr;          // no pool memory: the f32 engine below needs none

@@ -207,11 +207,11 @@ def test_gemm(ops, gpu_device, m, n, k, ta, tb):
 @pytest.mark.parametrize("k,n,tb", [(256, 256, True), (300, 256, True), (558, 200, True), (128, 128, False), (2, 256, True),
                                      (17, 40, False)])
 def test_gemm_split_engine_is_f32_accurate(ops, gpu_device, k, n, tb):
-    """Tall products with a small B run on the bf16 x 3 engine (m >= 512 rows): it must be as close to the f64
+    """Tall products with a small B run on the bf16 x 3 engine (m >= 16384 rows): it must be as close to the f64
     product as an f32 GEMM is (a few 1e-7 of the result's scale), also on edge tiles, partial k tiles, column slices
     and with alpha / beta / bias; below the row threshold the f32-MFMA engine gives the same numbers."""
     gen = torch.Generator().manual_seed(k * 1000 + n)
-    m = 2048 + 77
+    m = 16384 + 77
     a = torch.randn(m, k + 4, generator=gen)[:, 4:].to(gpu_device) if k % 4 == 0 else torch.randn(m, k, generator=gen).to(gpu_device)
     b = torch.randn((n, k) if tb else (k, n), generator=gen).to(gpu_device) * 0.1
     want = a.double() @ (b.double().t() if tb else b.double())
