@@ -297,8 +297,13 @@ int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg
                       float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                       void *stream);
 
-/* Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32), row-major:
+/* Dense fp32 GEMM on the matrix cores, row-major, f32 in / f32 out / f32 accumulation:
  *   C[m,n] = alpha * sum_k opA(A)[m,k] * opB(B)[k,n] + beta * C[m,n] (+ bias[n])
+ * Engines (chosen from the shape, results agree to f32 rounding): the f32-input MFMA (v_mfma_f32_32x32x2_f32), and two
+ * "bf16 x 3" engines that form the f32 product from six v_mfma_f32_32x32x16_bf16 over an exact three-way bf16 split
+ * of every operand (A row-major with m >= 16384 and a small B -- Linear forward / data gradient; trans_a = 1,
+ * trans_b = 0 with k >= 2048 -- weight gradients).  The first allocates a stream-ordered workspace of
+ * 6 * ceil(n/128)*128 * ceil(k/16)*16 bytes with hipMallocAsync on `stream` and frees it with hipFreeAsync.
  * trans_a / trans_b: 0 = stored as written, 1 = stored transposed (A is k x m / B is n x k).
  * Used for nn.Linear forward (trans_b = 1), its data gradient and its weight
  * gradient (model.py:111 etc., gate.py:24-25, linear_gat model.py:309).          */
