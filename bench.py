@@ -243,7 +243,7 @@ def main():
         side_slab = torch.empty((n_glob, dg), device=dev)
         row_block = torch.empty((world, n_loc, dg), device=dev)
         grad_block = torch.randn((world, n_loc, dg), device=dev)     # stand-in for the dense part's gradient
-        grad_slab = torch.empty((n_glob, dg), device=dev)
+        grad_slab = torch.randn((n_glob, dg), device=dev)
         grad_table = torch.empty((n_glob, dg), device=dev)
         fwd_rows, fwd_d, bwd_rows = n_glob, dg, n_glob
 
@@ -259,10 +259,15 @@ def main():
                 fs.forward_to_row_block(slab, side_slab=side_slab, out=row_block)
                 if ev is not None:
                     ev[1].record()
-            fs.to_column_slab(grad_block, out=grad_slab)       # the dense part's gradient back to column slabs
-            if ev is not None:
-                ev[2].record()
-            fs.backward(grad_slab, out=grad_table)             # A^T, my columns: no collective, no all-reduce
+            if args.no_overlap:
+                fs.to_column_slab(grad_block, out=grad_slab)   # the dense part's gradient back to column slabs
+                if ev is not None:
+                    ev[2].record()
+                fs.backward(grad_slab, out=grad_table)         # A^T, my columns: no collective, no all-reduce
+            else:                                              # the same in column pieces: A^T of piece p runs while
+                if ev is not None:                             # piece p + 1 is still on the links
+                    ev[2].record()
+                fs.backward_from_row_block(grad_block, out=grad_table)
             if ev is not None:
                 ev[3].record()
         ev_n = 4
@@ -372,8 +377,11 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
                          "bwd_launch_ms": float(bwd_ms.mean()),
-                         "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if mode != "rows" else None,
-                         "exchange_ms": float(xch_ms.mean()) if xch_ms is not None else None,
+                         "bwd_achieved_GBs": by_bwd / (bwd_ms.mean() * 1e-3) / 1e9
+                         if (mode == "none" or (mode == "features" and args.no_overlap)) else None,
+                         "exchange_ms": float(xch_ms.mean()) if (xch_ms is not None and mode == "features"
+                                                                   and args.no_overlap) else None,
+                         "bwd_includes_exchange": bool(mode == "features" and not args.no_overlap),
                          "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (its "
                                  "128-column slab launches together); it can exceed the ~6.3 TB/s of a plain HBM copy "
                                  "because slabs of the source table are partly served from the 256 MiB Infinity Cache, "

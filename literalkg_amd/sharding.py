@@ -171,6 +171,43 @@ class FeatureShardedAggregation:
             out[i, rlo:rhi].copy_(rcv)
         return side_slab, out
 
+    def backward_from_row_block(self, block: torch.Tensor, out: Optional[torch.Tensor] = None,
+                                pieces: Optional[int] = None) -> torch.Tensor:
+        """to_column_slab() fused with backward(): the gradient row block [G, rows_g, D/G] goes back to the column
+        layout in `pieces` COLUMN pieces (every column of A^T g is independent), all exchanges queued at once on the
+        collective's stream, and the transpose SpMM of piece p runs while piece p + 1 is still on the links.  A piece
+        is never narrower than 32 columns (128-byte gathers; narrower rows cost the same time per entry), so the
+        exchange of the N = 8 case (D/G = 32) stays in one piece.  Returns grad_ego[:, my columns]."""
+        g = self.graph
+        if pieces is None:
+            pieces = max(1, min(4, self.dg // 32))
+        while pieces > 1 and self.dg % pieces:
+            pieces -= 1
+        if out is None:
+            out = torch.empty((g.n, self.dg), dtype=block.dtype, device=block.device)
+        if self.world == 1 or pieces == 1:
+            return self.backward(self.to_column_slab(block), out=out)
+        w = self.dg // pieces
+        staged = block.is_cuda and dist.get_backend(self.group) == "gloo"     # host-only transport (rehearsal)
+        queue = []
+        for p in range(pieces):
+            src = block[:, :, p * w:(p + 1) * w].contiguous().view(self.world * self.my_rows, w)
+            dst = torch.empty((g.n, w), dtype=block.dtype, device=block.device)
+            if staged or not block.is_cuda:
+                self._all_to_all(dst, src, self.rows, [self.my_rows] * self.world)
+                work = None
+            else:
+                work = dist.all_to_all_single(dst, src, output_split_sizes=self.rows,
+                                              input_split_sizes=[self.my_rows] * self.world, group=self.group,
+                                              async_op=True)
+            queue.append((work, dst, src))
+        for p, (work, dst, _src) in enumerate(queue):
+            if work is not None:
+                work.wait()
+            self.spmm(g.t_rowptr, g.t_col, self.val_t, dst, g.n, out=out[:, p * w:(p + 1) * w],
+                      long_rows=g.long_rows(True))
+        return out
+
     def to_row_block(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """N x D/G column slab -> this rank's rows as G column panels, shape [G, rows_g, D/G]
         (panel i = columns of rank i).  One all-to-all."""

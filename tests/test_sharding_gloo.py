@@ -95,6 +95,9 @@ def _feature_worker(rank, world, port, n, d, q):
         ok &= torch.equal(gslab, gside[:, cols])
         gego = fs.backward(gslab)
         ok &= torch.allclose(gego, torch.matmul(a.t(), gside)[:, cols], rtol=1e-5, atol=1e-4)
+        for pieces in (None, 2, 3):                                    # exchange in column pieces, SpMM per piece
+            gego2 = fs.backward_from_row_block(gblock, pieces=pieces)
+            ok &= torch.allclose(gego2, gego, rtol=1e-6, atol=1e-6)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -48,6 +48,7 @@ def _worker(rank, world, port, q):
         gslab = fs.to_column_slab(gblock)
         ok &= torch.equal(gslab, gside[:, cols].contiguous())
         ok &= torch.allclose(fs.backward(gslab), want_grad[:, cols], rtol=1e-5, atol=1e-4)
+        ok &= torch.allclose(fs.backward_from_row_block(gblock, pieces=2), want_grad[:, cols], rtol=1e-5, atol=1e-4)
         # --- row-range sharding: own rows forward, all-reduced transpose backward (attention computed per shard)
         keep = (h >= lo) & (h < hi)
         mine = L.KGStructure.from_triples(n, h[keep], t[keep], r[keep], device=dev)
