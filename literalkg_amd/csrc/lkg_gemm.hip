@@ -1,5 +1,10 @@
-// Dense fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, bitwise a
-// k-ordered fmaf chain), plus the two grouped forms the TransR projection needs.
+// Dense fp32 GEMM on the gfx950 matrix cores, plus the two grouped forms the TransR projection needs.
+// Three engines behind one entry point (lkg_gemm_f32 picks by shape; all take and return f32, accumulate in f32):
+//   f32 engine     v_mfma_f32_32x32x2_f32 (exact f32, bitwise a k-ordered fmaf chain): every shape, every mode;
+//   split engine 1 v_mfma_f32_32x32x16_bf16 x 6 over a three-way bf16 split: A row-major, small pre-split B
+//                  (nn.Linear forward and data gradient);
+//   split engine 2 the same arithmetic, both operands k-major (weight gradients), transposing LDS reads.
+// The description below is the f32 engine's; the split engines are described where they are defined.
 //
 //   C[m,n] = alpha * sum_k opA(A)[m,k] * opB(B)[k,n] + beta * C[m,n] (+ bias[n])
 //
