@@ -1,6 +1,7 @@
 """GPU: the two multi-GPU schemes of literalkg_amd/sharding.py with the REAL HIP SpMM, rehearsed as 2 ranks sharing
 the one GPU of the test box over gloo (host-staged exchange).  Each rank checks its slab / row range against the
-single-device result it computes itself.  (RCCL itself needs several GPUs; the driver's scaling run exercises it.)"""
+single-device result it computes itself.  A second test runs the same checks over RCCL with one GPU per rank; it is
+skipped where fewer than two GPUs are visible (the driver's scaling run exercises RCCL in any case)."""
 import os
 import socket
 
@@ -13,15 +14,20 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nccl = backend == "nccl"
+    if nccl:      # one GPU per rank, RCCL over xGMI: the exchange paths bench.py uses at N > 1
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import literalkg_amd as L
         from literalkg_amd import ops
         from literalkg_amd.sharding import FeatureShardedAggregation, ShardedAggregation, shard_bounds
         from literalkg_amd.synth import make_kg
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", rank if nccl else 0)
         n, e, d = 30_000, 400_000, 128
         h, t, r = make_kg(n, e, seed=3)
         g = L.KGStructure.from_triples(n, h, t, r, device=dev)
@@ -64,7 +70,8 @@ def _worker(rank, world, port, q):
             x.copy_(hx)
             return type("W", (), {"wait": lambda self: None})()
         _orig = dist.all_reduce
-        dist.all_reduce = staged_all_reduce
+        if not nccl:
+            dist.all_reduce = staged_all_reduce
         try:
             grad = sh.backward(gside[lo:hi].contiguous())
         finally:
@@ -86,6 +93,29 @@ def test_two_ranks_on_one_gpu(gpu_device):
     q = ctx.Queue()
     world = 2
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)], res
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the test boxes have one)")
+def test_two_ranks_over_rccl(gpu_device):
+    """The same checks with one GPU per rank and backend "nccl" (RCCL): all-to-all with uneven splits, batched
+    point-to-point sends behind the SpMM, the async column-piece exchange of the backward, chunked all-reduce."""
+    import __graft_entry__ as ge
+    ge.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl")) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
