@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             constexpr bool FAST = decltype(fast_tag)::value;
             auto fetch_tile = [&](long tile) {
                 const long k0 = k_lo + tile * BK;
-                la.load(A, g.lda, m0, m_hi, k0, k_hi, t, FAST ? true : (a_al && m_full && k0 + BK <= k_hi && k0 % 4 == 0));
+                la.load(A, g.lda, m0, m_hi, k0, k_hi, t, FAST);   // a CONSTANT flag: the guarded form is branch-free too
                 const uint4 *src = bsrc + tile * (3 * PLANE / 8);
                 qb0 = src[0];
                 qb1 = src[PLANE / 8];
@@ -438,16 +438,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             LKG_TERM(2, 0) LKG_TERM(0, 2) LKG_TERM(1, 1) LKG_TERM(1, 0) LKG_TERM(0, 1) LKG_TERM(0, 0)
         };
 #undef LKG_TERM
+        // fast_tag: bit 1 = A tile loads unguarded, bit 0 = B tile loads unguarded (compile-time constants: a runtime
+        // flag would put a branch around the loads and cost a vmcnt(0) per step).  An edge column tile (n = 300: the
+        // text-literal weight gradient) keeps its A side on 16-byte loads this way.
         auto pipeline = [&](auto fast_tag, long first, long count) {
-            constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr int FAST = decltype(fast_tag)::value;
             auto fetch_tile = [&](long tile) {
                 const long k0 = k_lo + tile * BK;
-                if constexpr (FAST) {
-                    la.load(A, g.lda, m0, m_hi, k0, k_hi, t, true);
-                    lb.load(B, g.ldb, n0, g.n, k0, k_hi, t, true);
-                } else {
-                    fetch(la, lb, k0);
-                }
+                la.load(A, g.lda, m0, m_hi, k0, k_hi, t, (FAST & 2) != 0);
+                lb.load(B, g.ldb, n0, g.n, k0, k_hi, t, (FAST & 1) != 0);
                 __builtin_amdgcn_sched_barrier(0);
             };
             if (count <= 0) return;
@@ -482,12 +481,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             __syncthreads();
         };
         const long nt_all = (k_hi - k_lo + BK - 1) / BK, nt_full = (k_hi - k_lo) / BK;
-        if (a_al && b_al && m_full && n_full && (m0 % 4 == 0)) {
-            pipeline(std::true_type{}, 0, nt_full);
-            if (nt_all > nt_full) pipeline(std::false_type{}, nt_full, 1);
-        } else {
-            pipeline(std::false_type{}, 0, nt_all);
-        }
+        const bool a_fast = a_al && m_full && (m0 % 4 == 0), b_fast = b_al && n_full;
+        if (a_fast && b_fast)
+            pipeline(std::integral_constant<int, 3>{}, 0, nt_full);
+        else if (a_fast)
+            pipeline(std::integral_constant<int, 2>{}, 0, nt_full);
+        else if (b_fast)
+            pipeline(std::integral_constant<int, 1>{}, 0, nt_full);
+        else
+            pipeline(std::integral_constant<int, 0>{}, 0, nt_full);
+        if (nt_all > nt_full) pipeline(std::integral_constant<int, 0>{}, nt_full, 1);   // the partial last k tile
     } else {
         int buf = 0;
         if (k_lo < k_hi) {
