@@ -304,6 +304,7 @@ int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg
  * of every operand (A row-major with m >= 16384 and a small B -- Linear forward / data gradient; trans_a = 1,
  * trans_b = 0 with k >= 2048 -- weight gradients).  The first allocates a stream-ordered workspace of
  * 6 * ceil(n/128)*128 * ceil(k/16)*16 bytes with hipMallocAsync on `stream` and frees it with hipFreeAsync.
+ * LKG_GEMM_F32_ONLY=1 in the environment (read at the first call) keeps every product on the f32-input MFMA.
  * trans_a / trans_b: 0 = stored as written, 1 = stored transposed (A is k x m / B is n x k).
  * Used for nn.Linear forward (trans_b = 1), its data gradient and its weight
  * gradient (model.py:111 etc., gate.py:24-25, linear_gat model.py:309).          */

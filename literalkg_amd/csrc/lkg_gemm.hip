@@ -31,6 +31,8 @@
 //               (weight gradient  g_W[r] = X_r^T G_r)
 // Plain long-K / small-output products (nn.Linear weight gradients, K = n_entities) are split over K
 // with f32 atomic accumulation into a zeroed C.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -628,11 +630,17 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
     }
     // Split engine 1: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay
     // for the extra launch.  The plane workspace is stream-ordered (hipMallocAsync / hipFreeAsync on `s`).
+    // LKG_GEMM_F32_ONLY=1 in the environment keeps every product on the f32-input MFMA (the bit-exact k-ordered fmaf
+    // chain), e.g. to bisect a numerical difference; read once.
+    static const bool f32_only = [] {
+        const char *e = getenv("LKG_GEMM_F32_ONLY");
+        return e && e[0] == '1';
+    }();
     const int ktiles = (int)((k + BK - 1) / BK);
     const long ws_elems = (long)g.tiles_n * ktiles * 3 * PLANE;
     void *ws = nullptr;
     // (below ~16 k rows the call is bound by its host-side issue, ~12 us; workspace + pre-split add ~11 us of that)
-    if (!trans_a && k > 0 && m >= 16384 && (long)n * k <= (1L << 22)) {
+    if (!f32_only && !trans_a && k > 0 && m >= 16384 && (long)n * k <= (1L << 22)) {
         static bool pool_ready = false;     // keep freed workspaces in the pool instead of returning them at every sync
         if (!pool_ready) {
             int dev = 0;
@@ -654,7 +662,7 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
         g.bp = reinterpret_cast<const __bf16 *>(ws);
         g.ktiles_b = ktiles;
     }
-    g.split_km = (trans_a && !trans_b && k >= 2048) ? 1 : 0;   // long reductions over rows: weight gradients
+    g.split_km = (!f32_only && trans_a && !trans_b && k >= 2048) ? 1 : 0;   // long reductions over rows: weight gradients
     const int rc = run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
     if (ws && hipFreeAsync(ws, s) != hipSuccess) {
         lkg_set_error("lkg_gemm_f32: hipFreeAsync failed");
