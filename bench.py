@@ -382,8 +382,8 @@ def main():
                          "exchange_ms": float(xch_ms.mean()) if (xch_ms is not None and mode == "features"
                                                                    and args.no_overlap) else None,
                          "bwd_includes_exchange": bool(mode == "features" and not args.no_overlap),
-                         "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (its "
-                                 "128-column slab launches together); it can exceed the ~6.3 TB/s of a plain HBM copy "
+                         "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (one "
+                                 "launch covering its 128-column slabs); it can exceed the ~6.3 TB/s of a plain HBM copy "
                                  "because slabs of the source table are partly served from the 256 MiB Infinity Cache, "
                                  "whose hits the fabric-side FETCH_SIZE counter (traffic) still counts"},
         }

@@ -125,16 +125,23 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                                                         float *__restrict__ out, long ldo,
                                                         const float *__restrict__ self, long ld_self,
                                                         const int *__restrict__ long_rows, int n_long,
-                                                        int long_thresh) {
+                                                        int long_thresh, int blocks_per_slab, int slab_cols) {
     using ops = vec_ops<V>;
     __shared__ V part[4][CPL][LPE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool team = (int)blockIdx.x < n_long;     // workgroup-uniform
+    // several equal column slabs in ONE launch, slab-major (all workgroups of slab 0, then slab 1, ...): the slabs keep
+    // their temporal locality and the tail of one overlaps the start of the next (a separate launch costs ~25 us)
+    const int slab = (int)blockIdx.x / blocks_per_slab;
+    const int bid = (int)blockIdx.x - slab * blocks_per_slab;
+    x += (long)slab * slab_cols;
+    out += (long)slab * slab_cols;
+    if (self) self += (long)slab * slab_cols;
+    const bool team = bid < n_long;     // workgroup-uniform
     int row;
     if (team) {
-        row = long_rows[blockIdx.x];
+        row = long_rows[bid];
     } else {
-        row = ((int)blockIdx.x - n_long) * 4 + w;
+        row = (bid - n_long) * 4 + w;
         if (row >= n_rows) return;
     }
     const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
@@ -282,11 +289,12 @@ int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col
 template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
            int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
-           int long_thresh, hipStream_t s) {
+           int long_thresh, int n_slabs, int slab_cols, hipStream_t s) {
     const int64_t blocks = (n_rows + 3) / 4 + n_long;
-    hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows,
-                       nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self, long_rows, n_long,
-                       long_thresh);
+    LKG_REQUIRE(blocks * n_slabs < INT32_MAX, "lkg_spmm_csr_f32: grid too large");
+    hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0, s,
+                       (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
+                       long_rows, n_long, long_thresh, (int)blocks, slab_cols);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
@@ -294,13 +302,13 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
              int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
-             int long_thresh, hipStream_t s) {
+             int long_thresh, int n_slabs, int slab_cols, hipStream_t s) {
 #define LKG_GO(LPE, CPL, U)                                                                              \
     return (nchunk == LPE * CPL)                                                                         \
                ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
-                                              long_rows, n_long, long_thresh, s)                          \
+                                              long_rows, n_long, long_thresh, n_slabs, slab_cols, s)      \
                : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
-                                               long_rows, n_long, long_thresh, s)
+                                               long_rows, n_long, long_thresh, n_slabs, slab_cols, s)
     if (nchunk <= 8)   // rows of <= 32 floats: 8 rows per wave (see spmm_csr_grouped_kernel)
         return (nchunk == 8) ? launch_grouped<V, 8, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                             ld_self, long_rows, n_long, long_thresh, s)
@@ -340,12 +348,17 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     // Infinity Cache -- at the price of re-reading the (col, val) stream once per slab (+8 B per entry per slab).
     // The scalar (unaligned) path keeps up to 256 columns per launch.
     const int block_cols = vec ? 128 : 256;
+    if (d > block_cols && d % block_cols == 0)     // equal slabs: one launch, slab-major workgroup order
+        return vec ? dispatch<float4>(n_rows, block_cols / 4, rowptr, col, val, x, ldx, out, ldo, self, ld_self,
+                                      long_rows, n_long, long_thresh, d / block_cols, block_cols, s)
+                   : dispatch<float>(n_rows, block_cols, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
+                                     n_long, long_thresh, d / block_cols, block_cols, s);
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
-                                        self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, s)
+                                        self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
-                                       self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, s);
+                                       self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, s);
         if (rc != LKG_OK) return rc;
     }
     return LKG_OK;

@@ -14,9 +14,9 @@ def per_dispatch(d, kernel="spmm_csr_kernel"):
             acc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["Grid_Size"])))
     return {k: sorted(v) for k, v in acc.items()}
 
-# one lkg_spmm_csr_f32 call = SLABS kernel launches (128-column slabs: 2 at D=256); bench.py alternates forward and
-# backward calls, so the dispatches come as [fwd x SLABS, bwd x SLABS, ...]
-SLABS = int(os.environ.get("LKG_SLABS", "2"))
+# one lkg_spmm_csr_f32 call = SLABS kernel launches (1 since the equal 128-column slabs share one launch; 2 at D=256
+# for the r01_v5 / v6 library); bench.py alternates forward and backward calls: [fwd x SLABS, bwd x SLABS, ...]
+SLABS = int(os.environ.get("LKG_SLABS", "1"))
 
 
 def per_call(rows):
@@ -32,7 +32,7 @@ fwd_f, bwd_f = per_call(fetch)
 fwd_w, bwd_w = per_call(write)
 mean = lambda x: sum(x) / len(x)
 out = {
-    "kernel": f"spmm_csr_kernel<float4,32,1,4,true> x {SLABS} column slabs per call", "calls_sampled": len(fwd_f),
+    "kernel": f"spmm_csr_kernel<float4,32,1,4,true>, {SLABS} launch(es) per call (128-column slabs, slab-major)", "calls_sampled": len(fwd_f),
     "FETCH_SIZE_KiB_fwd": mean(fwd_f), "WRITE_SIZE_KiB_fwd": mean(fwd_w),
     "FETCH_SIZE_KiB_bwd": mean(bwd_f), "WRITE_SIZE_KiB_bwd": mean(bwd_w),
     "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
