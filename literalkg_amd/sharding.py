@@ -27,6 +27,7 @@ Backward : grad_ego = A^T grad_side.  The slice's transpose yields a partial N x
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -129,13 +130,13 @@ class FeatureShardedAggregation:
         Part p of round k computes rows of rank (rank + k) % G and receives from rank (rank - k) % G.
         Returns (side_slab [N, D/G], row_block [G, rows_g, D/G]).
 
-        pieces=None picks by group size: every extra row-range launch costs ~25 us (measured at 5 M rows x 100 M
-        entries x 32 columns: 1 launch 2.18 ms, 8: 2.32, 16: 2.53, 32: 2.95).  Up to 4 ranks the exchange is longer
-        than the SpMM (one xGMI link per peer), what counts is how early the first part leaves: 4 parts per peer.
-        From 8 ranks on the SpMM is the longer one and only the last part's transfer is exposed: 1 part per peer."""
+        On the GPU the row-range launches alternate between two side streams: back to back on ONE stream every extra
+        launch costs ~25 us of tail and gap (5 M rows x 100 M entries x 32 columns: 1 launch 2.16 ms, 8: 2.30,
+        32: 2.94), on two alternating streams the tail of one overlaps the start of the next (32 launches: 2.25 ms)
+        and each part still completes -- and leaves -- in order."""
         g = self.graph
         if pieces is None:
-            pieces = 4 if self.world <= 4 else 1
+            pieces = 4
         if side_slab is None:
             side_slab = torch.empty((g.n, self.dg), dtype=slab.dtype, device=slab.device)
         if out is None:
@@ -146,32 +147,46 @@ class FeatureShardedAggregation:
             n = hi - lo
             return lo + n * p // pieces, lo + n * (p + 1) // pieces
 
-        works, host = [], []
+        streams = []
+        if slab.is_cuda:
+            if not hasattr(self, "_side_streams"):
+                self._side_streams = [torch.cuda.Stream(device=slab.device) for _ in range(2)]
+            streams = self._side_streams
+            main = torch.cuda.current_stream(slab.device)
+            for st in streams:
+                st.wait_stream(main)
+        works, host, step = [], [], 0
         for p in range(pieces):
             for k in range(self.world):
                 j, i = (self.rank + k) % self.world, (self.rank - k) % self.world
                 lo, hi = part(self.cuts[j], self.cuts[j + 1], p)
-                if hi > lo:
-                    self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=side_slab[lo:hi],
-                              long_rows=g.long_rows(False, lo, hi))
-                if k == 0:
-                    mlo, mhi = part(0, self.my_rows, p)
-                    out[self.rank, mlo:mhi].copy_(side_slab[lo:hi])
-                    continue
-                rlo, rhi = part(0, self.my_rows, p)          # the matching part of MY rows, arriving from rank i
-                ops_ = []
-                if hi > lo:
-                    snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
-                    ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
-                if rhi > rlo:
-                    if staged:
-                        rcv = torch.empty((rhi - rlo, self.dg), dtype=out.dtype)
-                        host.append((rcv, i, rlo, rhi))
-                    else:
-                        rcv = out[i, rlo:rhi]
-                    ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
-                if ops_:
-                    works += dist.batch_isend_irecv(ops_)
+                ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
+                step += 1
+                with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this part
+                    if hi > lo:
+                        self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=side_slab[lo:hi],
+                                  long_rows=g.long_rows(False, lo, hi))
+                    if k == 0:
+                        mlo, mhi = part(0, self.my_rows, p)
+                        out[self.rank, mlo:mhi].copy_(side_slab[lo:hi])
+                        continue
+                    rlo, rhi = part(0, self.my_rows, p)          # the matching part of MY rows, arriving from rank i
+                    ops_ = []
+                    if hi > lo:
+                        snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
+                        ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
+                    if rhi > rlo:
+                        if staged:
+                            rcv = torch.empty((rhi - rlo, self.dg), dtype=out.dtype)
+                            host.append((rcv, i, rlo, rhi))
+                        else:
+                            rcv = out[i, rlo:rhi]
+                        ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
+                    if ops_:
+                        works += dist.batch_isend_irecv(ops_)
+        if streams:
+            for st in streams:
+                main.wait_stream(st)
         for w in works:
             w.wait()
         for rcv, i, rlo, rhi in host:
