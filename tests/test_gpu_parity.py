@@ -945,3 +945,37 @@ def test_mlp_head_matches_reference_fixture(L, gpu_device, name):
     with torch.no_grad():
         out_eval = m(heads, tails, device=gpu_device, mode="mlp")
     np.testing.assert_allclose(out_eval.cpu().numpy().reshape(-1), gd["out_eval"], rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- bench.py output contract
+def test_bench_prints_one_contract_line(gpu_device):
+    """`python bench.py` prints exactly one JSON line with the driver's keys plus `roofline` and `cpu_baseline`
+    (small graph here; the default run uses the BASELINE shape)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--entities", "50000", "--edges", "500000"], capture_output=True, text=True, timeout=600,
+                         cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["metric"] == "kg_edges_aggregated_per_sec" and j["unit"] == "edges/s"
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"]
+    assert j["config"]["spot_check"] == "ok"
+    assert abs(j["value"] - j["config"]["edge_aggregations_per_step"] / j["ms_per_step"] * 1e3) < 1e-6 * j["value"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
