@@ -2,7 +2,7 @@
 """The oracle (same ATen ops as the reference) on the host cores: update_att and one pre_training step at the C2 shape
 (1M entities / 10M triples, D=128, 1 gcn layer, TransR, 2049 triples).  Context numbers for DESIGN.md; slow (~1 min)."""
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import literalkg_oracle as O
 from literalkg_amd.synth import make_batch, make_kg

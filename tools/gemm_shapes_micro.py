@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""lkg_gemm_f32 on other widths (512, 64, 32, 128, 1024) against torch.  GPU box only; not part of the tests."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge; ge.build()
 from literalkg_amd import ops
 dev = torch.device("cuda:0")

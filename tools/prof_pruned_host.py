@@ -1,7 +1,9 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of the batch-pruned C2 step.  GPU box only; not part of the tests."""
 import os, sys, cProfile, pstats, io
 from types import SimpleNamespace
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge; ge.build()
 import literalkg_amd as L
 from literalkg_amd.synth import make_kg, make_batch

@@ -1,5 +1,7 @@
-import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Small-m GEMM calls: GPU time vs host-side issue time.  GPU box only; not part of the tests."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge; ge.build()
 from literalkg_amd import ops
 dev = torch.device("cuda:0")

@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Cost of cutting one SpMM into row-range launches (one stream vs alternating streams), N = 8 per-GPU shape.  GPU box only; not part of the tests."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge; ge.build()
 import literalkg_amd as L
 from literalkg_amd import ops
