@@ -100,7 +100,10 @@ int lkg_laplacian_f32(int64_t n_entities, int64_t n_raw, int64_t nnz, const int3
  * exactly the rows with > long_thresh entries (KGStructure builds it on the host).
  * self (nullable, n_rows x d, stride ld_self): out[i,:] = self[i,:] + sum ... , i.e. the
  * `ego + side` of the gcn / bi-interaction / gin layers (model.py:109, 123, 132) without a second
- * pass; in the backward the same flag adds the incoming gradient (d(ego+side)/d ego = I + A^T).   */
+ * pass; in the backward the same flag adds the incoming gradient (d(ego+side)/d ego = I + A^T).
+ * `self` may alias `out` (out += A x).  One kernel launch per call when d <= 128 or d is a multiple of 128
+ * (128-column slabs in slab-major workgroup order), else one launch per 128-column slab; rows of at most 32 floats
+ * take eight rows per wave.  Deterministic (no atomics): the same inputs give the same bits.          */
 int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                      const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                      const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
