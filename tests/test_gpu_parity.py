@@ -248,6 +248,27 @@ def test_gemm_weight_gradient_engine_is_f32_accurate(ops, gpu_device, m, n, k):
     torch.testing.assert_close(head.double(), want_head, rtol=1e-5, atol=2e-6 * float(want_head.abs().max()))
 
 
+def test_gemm_full_size_products_of_the_dense_layer(ops, gpu_device):
+    """The three products of one nn.Linear at the BASELINE shape (1 M rows, 256 x 256): every row tile of the forward
+    and the data gradient is checked on a strided row sample against f64, the weight gradient as a whole."""
+    gen = torch.Generator(device=gpu_device).manual_seed(11)
+    n, d = 1_000_000, 256
+    x = torch.randn((n, d), generator=gen, device=gpu_device)
+    gy = torch.randn((n, d), generator=gen, device=gpu_device)
+    w = torch.randn((d, d), generator=gen, device=gpu_device) * 0.06
+    b = torch.randn(d, generator=gen, device=gpu_device)
+    rows = torch.arange(0, n, 127, device=gpu_device)                 # 7875 rows, every 128-row tile is hit
+    y = ops.gemm(x, w, trans_b=True, bias=b)
+    want = x[rows].double() @ w.double().t() + b.double()
+    torch.testing.assert_close(y[rows].double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+    gx = ops.gemm(gy, w)
+    want = gy[rows].double() @ w.double()
+    torch.testing.assert_close(gx[rows].double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+    gw = ops.gemm(gy, x, trans_a=True)
+    want = gy.double().t() @ x.double()
+    torch.testing.assert_close(gw.double(), want, rtol=1e-5, atol=4e-6 * float(want.abs().max()))
+
+
 def test_gemm_split_k_and_slices(ops, gpu_device):
     gen = torch.Generator().manual_seed(3)
     gy = torch.randn(40000, 96, generator=gen)
