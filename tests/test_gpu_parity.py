@@ -108,6 +108,35 @@ def test_spmm_self_add_row_ranges_and_offsets(L, ops, O, gpu_device, d):
     torch.testing.assert_close(got_t.cpu(), torch.matmul(coo_of(gs, vs).t(), padded), rtol=1e-5, atol=5e-5)
 
 
+def test_spmm_narrow_rows_agree_with_the_wave_per_row_kernel_at_scale(L, ops, gpu_device):
+    """The rows-per-wave kernel (rows of <= 32 floats: the D/G slabs of the feature-sharded run) against the
+    wave-per-row kernel on a large skewed graph: the same 32 columns, once alone and once as the left half of a
+    64-column table, forward and transpose, long rows included -- bit-identical row sums are not required (other
+    summation order), 1e-5 relative is."""
+    rng = np.random.default_rng(77)
+    n, e = 2_000_000, 40_000_000
+    perm = rng.permutation(n)
+    h = perm[np.minimum((n * rng.random(e) ** 1.75).astype(np.int64), n - 1)]
+    t = rng.integers(0, n, e, dtype=np.int64)
+    g = L.KGStructure.from_triples(n, h, t, None, device=gpu_device)
+    del h, t
+    assert g.long_rows(False) is not None
+    gen = torch.Generator(device=gpu_device).manual_seed(5)
+    wide = torch.rand((n, 64), generator=gen, device=gpu_device)
+    wide[:, 32:] = 0
+    narrow = wide[:, :32].contiguous()
+    val = torch.rand(g.nnz, generator=gen, device=gpu_device)
+    val_t = ops.permute_values(val, g.t_perm)
+    for rp, cl, vl, lr in ((g.rowptr, g.col, val, g.long_rows(False)), (g.t_rowptr, g.t_col, val_t, g.long_rows(True))):
+        a = ops.spmm_raw(rp, cl, vl, narrow, n, long_rows=lr)
+        b = ops.spmm_raw(rp, cl, vl, wide, n, long_rows=lr)
+        assert float(b[:, 32:].abs().max()) == 0.0
+        scale = float(b.abs().max())
+        assert float((a - b[:, :32]).abs().max()) <= 1e-5 * scale
+        deg = (rp[1:] - rp[:-1])
+        empty = (deg == 0)
+        assert float(a[empty].abs().max()) == 0.0 if bool(empty.any()) else True
+
 def test_spmm_strided_views_and_autograd(L, ops, O, gpu_device):
     rng = np.random.default_rng(5)
     n, d = 300, 64
