@@ -290,6 +290,23 @@ def main():
             if ev is not None:
                 ev[2].record()
 
+    if mode == "features" and not args.no_overlap:
+        # The pipelined exchange (batched point-to-point sends behind the SpMM, async column pieces) could not be run
+        # over RCCL on the one-GPU development boxes: if it RAISES here (on every rank alike), fall back to the plain
+        # all-to-all form instead of losing the run.  The ranks agree on the outcome before going on.
+        ok, why = 1.0, ""
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as exc:      # noqa: BLE001 -- any failure of the optional path
+            ok, why = 0.0, repr(exc)
+        flag = torch.tensor([ok], device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag) == 0.0:
+            if rank == 0:
+                print(f"bench.py: pipelined exchange unavailable ({why or 'failed on another rank'}); "
+                      f"using the plain all-to-all form", file=sys.stderr)
+            args.no_overlap = True
     for _ in range(max(args.warmup, 1)):
         step()
     # spot check: 8 of this rank's output rows (after the exchange, in feature mode) against a direct evaluation
