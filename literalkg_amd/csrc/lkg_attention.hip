@@ -270,10 +270,7 @@ int dispatch(const EsArgs &a, hipStream_t s) {
     if (nchunk <= 8) return launch<V, 8, 1, 2>(a, s);
     if (nchunk <= 16) return launch<V, 16, 1, 2>(a, s);
     if (nchunk <= 32) return launch<V, 32, 1, 2>(a, s);
-#ifndef LKG_ATT_U64
-#define LKG_ATT_U64 2
-#endif
-    if (nchunk <= 64) return launch<V, 64, 1, LKG_ATT_U64>(a, s);
+    if (nchunk <= 64) return launch<V, 64, 1, 2>(a, s);   // (after the VALU reductions: U=3 the same, U=4 slower)
     if (nchunk <= 128) return launch<V, 64, 2, 2>(a, s);
     if (nchunk <= 192) return launch<V, 64, 3, 2>(a, s);
     if (nchunk <= 256) return launch<V, 64, 4, 1>(a, s);
