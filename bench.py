@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- LiteralKG aggregation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+With --gpus N > 1 and no torch.distributed environment the script starts its own N workers (a child
+`python -m torch.distributed.run`, before anything touches the GPU) and passes their JSON line and exit code through;
+under torch.distributed.run it is one rank per GPU.
 
 Metric (BASELINE.json): KG edges aggregated / s, 1 GAT layer, dim 256, plus % of the 8 TB/s HBM roofline.
 A STEP is one pass of the aggregation layer's sparse hot path over the whole graph:
     forward   side      = A_in   @ ego        (lkg_spmm_csr_f32 on the CSR,  model.py:106)
     backward  grad_ego  = A_in^T @ grad_side  (the same kernel on the CSC,   autograd of model.py:106)
-    N > 1     + the sum of the partial entity-gradient tables over ranks (RCCL all-reduce over xGMI)
+    N > 1     + the exchange step of the sharding scheme (both schemes are measured, see --sharding)
 A_in holds a real refreshed attention (edge logits + row softmax from the fused K1+K2 kernel).
 `value` counts one aggregation per edge per pass: 2 * E edge-aggregations per step / wall time.
 Workload at N = 1: synthetic KG 1M entities / 10M edges, D = 256 (the config the metric is quoted on);
-at N > 1 every rank owns a head-row range of 625k entities / 12.5M edges (N = 8 is BASELINE config[3]:
-5M entities / 100M edges) and holds a full replica of the source table (weak scaling).
+at N > 1 every rank contributes a head-row range of 625k entities / 12.5M edges (N = 8 is BASELINE config[3]:
+5M entities / 100M edges): weak scaling.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SPMM_SOURCE = os.path.join(ROOT, "literalkg_amd", "csrc", "lkg_spmm.hip")
 
 
 def algorithmic_bytes(nnz, n_out_rows, d):
@@ -36,18 +44,26 @@ def algorithmic_bytes(nnz, n_out_rows, d):
     return nnz * (4 * d + 8) + n_out_rows * 4 * d + 4 * (n_out_rows + 1)
 
 
+def source_sha(path=SPMM_SOURCE):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def pmc_traffic(by):
-    """HBM bytes per forward launch from the newest committed rocprofv3 --pmc summary (tools/pmc_traffic.py;
-    counters cannot be read from inside the process).  Used only when it was taken on this workload."""
+    """HBM bytes per forward launch from the newest committed rocprofv3 --pmc summary (tools/pmc_traffic.py; the
+    counters cannot be read from inside the process).  Reported only when that summary was taken on THIS kernel
+    source (sha of lkg_spmm.hip stored in the summary) and on this workload; otherwise null."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None, None
+        return None, "no PMC summary committed"
     rec = json.load(open(files[-1]))
+    name = os.path.relpath(files[-1], ROOT)
+    if rec.get("spmm_source_sha16") != source_sha():
+        return None, f"{name} was taken on another lkg_spmm.hip ({rec.get('spmm_source_sha16')} != {source_sha()})"
     tr = rec.get("traffic_bytes_fwd")
     if tr is None or abs(tr - by) > 0.25 * by:      # different shape: not comparable
-        return None, None
-    return tr, os.path.relpath(files[-1], ROOT)
+        return None, f"{name} was taken on another workload"
+    return tr, name
 
 
 def cpu_baseline(g, val, n, d, seed):
@@ -77,12 +93,27 @@ def cpu_baseline(g, val, n, d, seed):
                       f"{cores} threads"}
 
 
+def _timed(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    ms = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ms))
+
+
 def whole_path_timings(h, t, r, n, d, dev):
     """Context numbers for the same graph (SURVEY.md 8d ii-iv), outside the headline metric: the drop-in
-    module's update_att, and one pre_training step (1 gcn layer, D=d, TransR, 2049 triples) forward /
-    forward+backward.  Median of 10 after 3 warm-ups, host-timed around a device sync."""
+    module's update_att, one pre_training step (1 gcn layer, D=d, TransR, 2049 triples) forward /
+    forward+backward, one aggregation layer, the layer's Linear and the literal gate against the MFMA peak.
+    Median of 10 after 3 warm-ups, host-timed around a device sync."""
     from types import SimpleNamespace
     import literalkg_amd as L
+    from literalkg_amd import ops
     from literalkg_amd.synth import make_batch
     cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=d, relation_dim=d, scale_gat_dim=None,
                           use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=1,
@@ -93,57 +124,117 @@ def whole_path_timings(h, t, r, n, d, dev):
     hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
     batch = [torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3)]
 
-    def timed(fn, reps=10):
-        for _ in range(3):
-            fn()
-        ms = []
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            ms.append((time.perf_counter() - t0) * 1e3)
-        return float(np.median(ms))
-
     rel = list(range(16))
-    upd = timed(lambda: model(hd, td, rd, rel, device=dev, mode="update_att"))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model(hd, td, rd, rel, device=dev, mode="update_att")
+    torch.cuda.synchronize()
+    upd_first = (time.perf_counter() - t0) * 1e3           # includes the structure build of the edge lists
+    upd = _timed(lambda: model(hd, td, rd, rel, device=dev, mode="update_att"))
     model.train()
 
     def fwd_bwd():
         model.zero_grad(set_to_none=True)
         model(*batch, device=dev, mode="pre_training").backward()
     with torch.no_grad():
-        fwd = timed(lambda: model(*batch, device=dev, mode="pre_training"))
-    step = timed(fwd_bwd)
+        fwd = _timed(lambda: model(*batch, device=dev, mode="pre_training"))
+    step = _timed(fwd_bwd)
     model.prune_to_batch = True          # exact: layers evaluated on the batch's L-hop frontier only
-    pruned = timed(fwd_bwd)
+    pruned = _timed(fwd_bwd)
     model.prune_to_batch = False
-    # (ii) one aggregation layer forward (a1 + a2): SpMM(+self), Linear on the f32 MFMA GEMM, LeakyReLU/LayerNorm/
-    # dropout/normalise epilogue; and the dense GEMM of that layer alone against the f32 MFMA peak
-    from literalkg_amd import ops
+    # (ii) one aggregation layer forward (a1 + a2): SpMM(+self), Linear on the MFMA GEMM, LeakyReLU/LayerNorm/
+    # dropout/normalise epilogue; and the dense GEMM of that layer alone against the MFMA peak
     att = model._attention()
     ego = model.entity_embed.weight.detach()
     layer = model.aggregator_layers[0]
     with torch.no_grad():
-        layer_ms = timed(lambda: layer(ego, att, [ego], model.lamda, model.alpha, 1))
+        layer_ms = _timed(lambda: layer(ego, att, [ego], model.lamda, model.alpha, 1))
         w, b = layer.linear.weight.detach(), layer.linear.bias.detach()
-        gemm_ms = timed(lambda: ops.gemm(ego, w, trans_b=True, bias=b))
+        gemm_ms = _timed(lambda: ops.gemm(ego, w, trans_b=True, bias=b))
     gemm_tf = 2.0 * n * d * d / gemm_ms / 1e9
     e = len(h)
-    return {"config": f"LiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, same graph",
-            "update_att_ms": upd, "update_att_edges_per_s": e / upd * 1e3,
-            "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
-            "pre_training_step_edges_per_s": e / step * 1e3,
-            "pre_training_forward_backward_ms_prune_to_batch": pruned,
-            "layer_forward_ms": layer_ms, "layer_forward_edges_per_s": e / layer_ms * 1e3,
-            "roofline_gemm": {"bound": "mfma",
-                              "kernel": f"gemm_kernel<split> Linear forward {n}x{d}x{d}: f32 product as 6 "
-                                        f"v_mfma_f32_32x32x16_bf16 per 16 k (bf16 x 3 operand split, f32-accurate)",
-                              "achieved": gemm_tf, "peak": 2500.0 / 6, "unit": "TFLOP/s (f32-equivalent)",
-                              "frac": gemm_tf / (2500.0 / 6),
-                              "note": "peak = dense bf16 MFMA peak / 6 products; the f32-input MFMA it replaces peaks at "
-                                      "157.3 TFLOP/s; memory floor of this shape (read x, write y) is ~0.31 ms",
-                              "avg_launch_ms": gemm_ms}}
+    out = {"config": f"LiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, same graph",
+           "update_att_first_call_ms": upd_first,
+           "update_att_ms": upd, "update_att_edges_per_s": e / upd * 1e3,
+           "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
+           "pre_training_step_edges_per_s": e / step * 1e3,
+           "pre_training_forward_backward_ms_prune_to_batch": pruned,
+           "layer_forward_ms": layer_ms, "layer_forward_edges_per_s": e / layer_ms * 1e3,
+           "roofline_gemm": {"bound": "mfma",
+                             "kernel": f"gemm_kernel<split> Linear forward {n}x{d}x{d}: f32 product as 6 "
+                                       f"v_mfma_f32_32x32x16_bf16 per 16 k (bf16 x 3 operand split, f32-accurate)",
+                             "achieved": gemm_tf, "peak": 2500.0 / 6, "unit": "TFLOP/s (f32-equivalent)",
+                             "frac": gemm_tf / (2500.0 / 6),
+                             "note": "peak = dense bf16 MFMA peak / 6 products; the f32-input MFMA it replaces peaks at "
+                                     "157.3 TFLOP/s; memory floor of this shape (read x, write y) is ~0.31 ms",
+                             "avg_launch_ms": gemm_ms}}
+    del model, att, layer
+    out["gate"] = gate_timing(n, d, dev)
+    return out
+
+
+def gate_timing(n, d, dev):
+    """K6 at the C3 shape: GateMul forward over n x (d + 2 + 300) (gate.py:22-28)."""
+    import literalkg_amd as L
+    gate = L.GateMul(d, 2, 300).to(dev)
+    x = torch.randn(n, d, device=dev) * 0.05
+    num = torch.rand(n, 2, device=dev)
+    txt = torch.randn(n, 300, device=dev)
+    out = torch.empty(n, d, device=dev)
+    with torch.no_grad():
+        ms = _timed(lambda: gate(x, num, txt, out))
+    flops = 2.0 * n * (d + 302) * d * 2
+    alg = 4.0 * n * (d + 302 + d)
+    return {"kernel": f"GateMul forward {n} x ({d}+2+300) -> {d}", "ms": ms,
+            "tflops_f32_equivalent": flops / ms / 1e9, "frac_of_bf16x3_peak": flops / ms / 1e9 / (2500.0 / 6),
+            "algorithmic_bytes": alg, "algorithmic_GBs": alg / ms / 1e6}
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N workers as a CHILD process (nothing in this
+    process has touched the GPU yet, and the child is a new program, not an exec of this one)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def spot_rows(g, val, table, rows):
+    """side[rows] evaluated with plain torch ops from the full table (the bench's own sanity check of a sharded
+    result; it launches no kernel of the library, so the profiles of this script hold the timed launches only)."""
+    rp = g.host("rowptr")
+    out = []
+    for i in rows:
+        sl = slice(int(rp[i]), int(rp[i + 1]))
+        out.append((val[sl][:, None] * table[g.col[sl].long()]).sum(0, keepdim=True))
+    return torch.cat(out)
+
+
+class Timer:
+    """K timed steps between barrier + device sync on both sides; MAX over ranks."""
+
+    def __init__(self, world, cdev):
+        self.world, self.cdev = world, cdev
+
+    def run(self, step, steps, n_events):
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_events)] for _ in range(steps)]
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(events[i])
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if self.world > 1:
+            el = el.to(self.cdev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el), events
 
 
 def main():
@@ -157,34 +248,37 @@ def main():
     ap.add_argument("--skew", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the whole-path context timings (N=1)")
-    ap.add_argument("--chunks", type=int, default=4, help="rows mode: tail-row chunks of the backward (comm overlap)")
-    ap.add_argument("--sharding", default="features", choices=["features", "rows"],
-                    help="N>1: 'features' = column-sharded tables, no collective in the SpMM, all-to-all exchange; "
-                         "'rows' = head-row ranges + all-reduce of the entity-gradient table")
+    ap.add_argument("--chunks", type=int, default=4, help="rows scheme: tail-row chunks of the backward (comm overlap)")
+    ap.add_argument("--sharding", default="both", choices=["both", "features", "rows"],
+                    help="N>1: 'features' = column-sharded tables, no collective in the SpMM, all-to-all exchange (the "
+                         "headline `value`); 'rows' = head-row ranges + all-reduce of the entity-gradient table (the "
+                         "scheme BASELINE.json's north star names); 'both' (default) times features for `value` and "
+                         "rows next to it in `rows_scheme`")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="features mode: plain all-to-all after the SpMM instead of per-range sends behind it")
+                    help="features scheme: plain all-to-all after the SpMM instead of per-range sends behind it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and talk over gloo (N>1 code path on a 1-GPU box); "
                          "the numbers of such a run are meaningless")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
+            cdev = torch.device("cpu")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -195,6 +289,7 @@ def main():
         dist.barrier()
     import literalkg_amd as L
     from literalkg_amd import ops
+    from literalkg_amd._native import LkgError
     from literalkg_amd.sharding import FeatureShardedAggregation, ShardedAggregation
     from literalkg_amd.synth import make_kg, xavier_table
 
@@ -203,7 +298,8 @@ def main():
     e_loc = args.edges or (10_000_000 if world == 1 else 12_500_000)
     n_glob = n_loc * world
     lo, hi = rank * n_loc, (rank + 1) * n_loc
-    mode = "none" if world == 1 else args.sharding
+    schemes = ["none"] if world == 1 else (["features", "rows"] if args.sharding == "both" else [args.sharding])
+    timer = Timer(world, cdev)
 
     # every rank draws the triples of ITS head rows (heads inside [lo, hi), tails over all entities)
     t0 = time.perf_counter()
@@ -213,31 +309,68 @@ def main():
         hl, _, r = make_kg(n_loc, e_loc, args.skew, seed=2022 + rank)
         h = hl + lo
         t = np.random.default_rng(4044 + rank).integers(0, n_glob, len(h), dtype=np.int64)
-    if mode == "features":      # feature sharding replicates the (small) structure: exchange the triple lists
-        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    g_own = L.KGStructure.from_triples(n_glob, h, t, r, device=dev)       # this rank's head rows (N = 1: everything)
+    t_build = time.perf_counter() - t0
+    relemb = xavier_table(16, d, dev, seed=7)
+    probe = [lo + int(x) for x in np.random.default_rng(rank).integers(0, n_loc, 8)]
+
+    def reduce_flags(valid, nnz, sum_nnz):
+        valid_t = torch.tensor([float(valid)])
+        nnz_t = torch.tensor([nnz], dtype=torch.int64)
+        if world > 1:
+            valid_t, nnz_t = valid_t.to(cdev), nnz_t.to(cdev)
+            dist.all_reduce(valid_t, op=dist.ReduceOp.MIN)
+            if sum_nnz:
+                dist.all_reduce(nnz_t, op=dist.ReduceOp.SUM)
+        return float(valid_t) == 1.0, int(nnz_t)
+
+    # ------------------------------------------------------------------ N = 1 and the row-range scheme
+    def run_rows():
+        ent = xavier_table(n_glob, d, dev, seed=2022)              # full replica of the source table on every rank
+        val, _ = ops.edge_softmax(g_own, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
+        shard = ShardedAggregation(g_own, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
+        want = spot_rows(g_own, val, ent, probe)
+        grad_side = torch.randn((hi - lo, d), device=dev)
+        side = torch.empty((hi - lo, d), device=dev)
+        grad_table = torch.empty((n_glob, d), device=dev)
+
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record()
+            shard.forward(ent, out=side)
+            if ev is not None:
+                ev[1].record()
+            shard.backward(grad_side, out=grad_table)          # N > 1: chunked SpMM overlapped with the all-reduce
+            if ev is not None:
+                ev[2].record()
+        for _ in range(max(args.warmup, 1)):
+            step()
+        ok = torch.allclose(side[[i - lo for i in probe]], want, rtol=1e-4, atol=1e-6)
+        elapsed, events = timer.run(step, args.steps, 3)
+        ok, total = reduce_flags(ok, g_own.nnz, True)
+        fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+        bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+        res = {"elapsed": elapsed, "total_entries": total, "valid": ok, "fwd_ms": fwd, "bwd_ms": bwd,
+               "fwd_bytes": algorithmic_bytes(g_own.nnz, hi - lo, d), "bwd_bytes": algorithmic_bytes(g_own.nnz, n_glob, d),
+               "val": val, "exchange": "none" if world == 1 else
+               f"all_reduce of the N x D entity-gradient table in {len(shard.chunks)} tail-row chunks behind the SpMM"}
+        return res
+
+    # ------------------------------------------------------------------ feature sharding
+    def run_features():
+        # feature sharding replicates the (small) structure: exchange the triple lists
         mine = torch.from_numpy(np.stack([h, t, r])).to(cdev).reshape(-1)
         every = torch.empty(world * mine.numel(), dtype=torch.int64, device=cdev)
         dist.all_gather_into_tensor(every, mine)
         every = every.view(world, 3, -1)
-        h, t, r = (every[:, i].reshape(-1).cpu().numpy() for i in range(3))
+        ha, ta, ra = (every[:, i].reshape(-1).cpu().numpy() for i in range(3))
         del every, mine
-    g = L.KGStructure.from_triples(n_glob, h, t, r, device=dev)
-    t_build = time.perf_counter() - t0
-
-    ent = xavier_table(n_glob, d, dev, seed=2022)              # same table on every rank
-    relemb = xavier_table(16, d, dev, seed=7)
-    ev_n = 3
-
-    def expected_rows(val_for, rows):
-        """side[rows] recomputed one row at a time from the full table (spot check of the sharded result)."""
-        return torch.cat([ops.spmm_raw(g.rowptr[i:i + 2], g.col, val_for, ent, 1) for i in rows])
-    probe = [lo + int(x) for x in np.random.default_rng(rank).integers(0, n_loc, 8)]
-    if mode == "features":
-        # real attention values for the whole graph (replicated, like the structure)
-        val, _ = ops.edge_softmax(g, ent, relemb)
+        g = L.KGStructure.from_triples(n_glob, ha, ta, ra, device=dev)
+        ent = xavier_table(n_glob, d, dev, seed=2022)
+        val, _ = ops.edge_softmax(g, ent, relemb)                  # replicated, like the structure
         fs = FeatureShardedAggregation(g, val, rank, world, d, [i * n_loc for i in range(world + 1)])
         slab = fs.column_slab(ent)
-        want_probe = expected_rows(val, probe)
+        want = spot_rows(g, val, ent, probe)
         del ent
         dg = fs.dg
         side_slab = torch.empty((n_glob, dg), device=dev)
@@ -245,12 +378,12 @@ def main():
         grad_block = torch.randn((world, n_loc, dg), device=dev)     # stand-in for the dense part's gradient
         grad_slab = torch.randn((n_glob, dg), device=dev)
         grad_table = torch.empty((n_glob, dg), device=dev)
-        fwd_rows, fwd_d, bwd_rows = n_glob, dg, n_glob
+        plain = [bool(args.no_overlap)]
 
         def step(ev=None):
             if ev is not None:
                 ev[0].record()
-            if args.no_overlap:
+            if plain[0]:
                 fs.forward(slab, out=side_slab)                # all edges, my columns: no collective
                 if ev is not None:
                     ev[1].record()
@@ -259,7 +392,7 @@ def main():
                 fs.forward_to_row_block(slab, side_slab=side_slab, out=row_block)
                 if ev is not None:
                     ev[1].record()
-            if args.no_overlap:
+            if plain[0]:
                 fs.to_column_slab(grad_block, out=grad_slab)   # the dense part's gradient back to column slabs
                 if ev is not None:
                     ev[2].record()
@@ -270,159 +403,125 @@ def main():
                 fs.backward_from_row_block(grad_block, out=grad_table)
             if ev is not None:
                 ev[3].record()
-        ev_n = 4
-    else:
-        val, _ = ops.edge_softmax(g, ent, relemb, row_lo=lo, row_hi=hi)     # real attention values, own rows
-        shard = ShardedAggregation(g, val, lo, hi, n_chunks=args.chunks if world > 1 else 1)
-        want_probe = expected_rows(val, probe)
-        grad_side = torch.randn((hi - lo, d), device=dev)
-        side = torch.empty((hi - lo, d), device=dev)
-        grad_table = torch.empty((n_glob, d), device=dev)
-        fwd_rows, fwd_d, bwd_rows = hi - lo, d, n_glob
 
-        def step(ev=None):
-            if ev is not None:
-                ev[0].record()
-            shard.forward(ent, out=side)
-            if ev is not None:
-                ev[1].record()
-            shard.backward(grad_side, out=grad_table)          # chunked SpMM overlapped with the all-reduce
-            if ev is not None:
-                ev[2].record()
-
-    if mode == "features" and not args.no_overlap:
-        # The pipelined exchange (batched point-to-point sends behind the SpMM, async column pieces) could not be run
-        # over RCCL on the one-GPU development boxes: if it RAISES here (on every rank alike), fall back to the plain
-        # all-to-all form instead of losing the run.  The ranks agree on the outcome before going on.
-        ok, why = 1.0, ""
-        try:
+        exchange = "all_to_all" if plain[0] else "pipelined"
+        if not plain[0]:
+            # The pipelined exchange (batched point-to-point sends behind the SpMM, async column pieces) had not run
+            # over RCCL before this script's first multi-GPU run.  Only an error of the COLLECTIVE LIBRARY switches to
+            # the plain all-to-all form (and says so in the JSON); anything else (a kernel launch error, a shape bug)
+            # is re-raised.  The ranks agree on the outcome; if that agreement itself fails the run exits non-zero.
+            ok, why = 1.0, ""
+            try:
+                step()
+                torch.cuda.synchronize()
+            except LkgError:
+                raise
+            except dist.DistError as exc:
+                ok, why = 0.0, f"{type(exc).__name__}: {exc}"
+            flag = torch.tensor([ok], device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag) == 0.0:
+                plain[0] = True
+                exchange = f"all_to_all (fallback: {(why or 'failed on another rank')[:200]})"
+        for _ in range(max(args.warmup, 1)):
             step()
-            torch.cuda.synchronize()
-        except Exception as exc:      # noqa: BLE001 -- any failure of the optional path
-            ok, why = 0.0, repr(exc)
-        flag = torch.tensor([ok], device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag) == 0.0:
-            if rank == 0:
-                print(f"bench.py: pipelined exchange unavailable ({why or 'failed on another rank'}); "
-                      f"using the plain all-to-all form", file=sys.stderr)
-            args.no_overlap = True
-    for _ in range(max(args.warmup, 1)):
-        step()
-    # spot check: 8 of this rank's output rows (after the exchange, in feature mode) against a direct evaluation
-    if mode == "features":
-        got_probe = torch.cat([row_block[:, i - lo, :].reshape(1, -1) for i in probe])
-    else:
-        got_probe = side[[i - lo for i in probe]]
-    valid = torch.tensor([float(torch.allclose(got_probe, want_probe, rtol=1e-4, atol=1e-6))])
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(ev_n)] for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64)
-    nnz_all = torch.tensor([g.nnz], dtype=torch.int64)
-    if world > 1:
-        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        el, nnz_all, valid = el.to(cdev), nnz_all.to(cdev), valid.to(cdev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(valid, op=dist.ReduceOp.MIN)
-        if mode == "rows":
-            dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
-    elapsed = float(el)
-    total_entries = int(nnz_all)
+        got = torch.cat([row_block[:, i - lo, :].reshape(1, -1) for i in probe])
+        ok = torch.allclose(got, want, rtol=1e-4, atol=1e-6)
+        elapsed, events = timer.run(step, args.steps, 4)
+        ok, total = reduce_flags(ok, g.nnz, False)
 
-    # feature mode: the same loop without the layout exchange (the SpMM hot path alone, which needs no collective),
-    # reported next to `value` so that the cost of the exchange is visible; not part of the timed region above
-    agg_only_ms = None
-    if mode == "features":
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        kev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-        for e3 in kev:
-            e3[0].record()
+        # the same loop without the layout exchange (the SpMM hot path alone, which needs no collective): the
+        # roofline of the dominant KERNEL comes from here (in the timed step the forward is cut into row-range
+        # launches interleaved with the sends); not part of the timed region above
+        def bare(ev):
+            ev[0].record()
             fs.forward(slab, out=side_slab)
-            e3[1].record()
+            ev[1].record()
             fs.backward(grad_slab, out=grad_table)
-            e3[2].record()
-        torch.cuda.synchronize()
-        dist.barrier()
-        ao = torch.tensor([time.perf_counter() - t1], dtype=torch.float64).to(cdev)
-        dist.all_reduce(ao, op=dist.ReduceOp.MAX)
-        agg_only_ms = float(ao) / args.steps * 1e3
+            ev[2].record()
+        bare_elapsed, kev = timer.run(bare, args.steps, 3)
+        xch = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if plain[0] else None
+        return {"elapsed": elapsed, "total_entries": total, "valid": ok,
+                "fwd_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in kev])),
+                "bwd_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in kev])),
+                "step_bwd_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in events])),
+                "fwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg), "bwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg),
+                "spmm_only_ms": bare_elapsed / args.steps * 1e3, "exchange_ms": xch, "exchange": exchange, "dg": dg}
 
-    # dominant kernel = the forward SpMM launch; HIP events on the launch stream (torch's current stream)
-    fwd_ms = np.array([ev[0].elapsed_time(ev[1]) for ev in events])
-    bwd_ms = np.array([ev[-2].elapsed_time(ev[-1]) for ev in events])
-    xch_ms = np.array([ev[1].elapsed_time(ev[2]) for ev in events]) if ev_n == 4 else None
-    by = algorithmic_bytes(g.nnz, fwd_rows, fwd_d)
-    by_bwd = algorithmic_bytes(g.nnz, bwd_rows, fwd_d)
-    kernel_bwd_ms = None
-    if mode == "features":
-        # the roofline of the dominant KERNEL: the single-launch forward of the exchange-free loop above (in the
-        # timed step the forward is cut into row-range launches interleaved with the sends)
-        fwd_ms = np.array([e3[0].elapsed_time(e3[1]) for e3 in kev])
-        kernel_bwd_ms = float(np.mean([e3[1].elapsed_time(e3[2]) for e3 in kev]))
-    achieved = by / (fwd_ms.mean() * 1e-3) / 1e9
+    results = {}
+    for scheme in schemes:
+        results[scheme] = run_features() if scheme == "features" else run_rows()
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(by) if world == 1 else (None, None)
+        head = schemes[0]
+        res = results[head]
+        total = res["total_entries"]
+        achieved = res["fwd_bytes"] / (res["fwd_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(res["fwd_bytes"]) if world == 1 else (None, "N > 1: not collected")
+        workload = (f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
+                    + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
+                       "features": " + RCCL exchange (column slab <-> row block) both ways"}[head]
+                    + f"; synthetic KG {n_glob} entities / {total} stored (h,t) entries "
+                      f"({e_loc * world} triples, R=16, {args.skew} heads)")
         out = {
             "metric": "kg_edges_aggregated_per_sec",
-            "value": 2 * total_entries * args.steps / elapsed,
+            "value": 2 * total * args.steps / res["elapsed"],
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": res["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "REHEARSAL (gloo, one GPU): not a measurement",
+            "dtype": "f32",
+            "data": "synthetic" if not args.rehearse_on_one_gpu else "REHEARSAL (gloo, one GPU): not a measurement",
             "config": {
-                "workload": f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
-                            + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
-                               "features": " + RCCL all-to-all (column slab <-> row block) both ways"}[mode]
-                            + f"; synthetic KG {n_glob} entities / {total_entries} stored (h,t) entries "
-                              f"({e_loc * world} triples, R=16, {args.skew} heads)",
-                "entities": n_glob, "stored_entries": total_entries, "triples": e_loc * world, "dim": d,
-                "edge_aggregations_per_step": 2 * total_entries, "passes": ["spmm_csr_fwd", "spmm_csc_bwd"],
-                "sharding": {"none": "none", "rows": f"head-row ranges x{world}, replicated table, gradient all-reduce",
+                "workload": workload,
+                "entities": n_glob, "stored_entries": total, "triples": e_loc * world, "dim": d,
+                "edge_aggregations_per_step": 2 * total, "passes": ["spmm_csr_fwd", "spmm_csc_bwd"],
+                "sharding": {"none": "none",
+                             "rows": f"head-row ranges x{world}, replicated table, gradient all-reduce",
                              "features": f"feature columns x{world} (D/G={d // world}), replicated structure, "
-                                         f"all-to-all exchange"}[mode],
+                                         f"column slab <-> row block exchange"}[head],
+                "exchange": res["exchange"],
                 "skew": args.skew,
                 "host_graph_build_s": round(t_build, 2),
-                "spot_check": "ok" if float(valid) == 1.0 else "MISMATCH: 8 output rows per rank differ from a direct evaluation",
-                "spmm_only_ms_per_step": agg_only_ms,
-                "spmm_only_edges_per_s": (2 * total_entries / agg_only_ms * 1e3) if agg_only_ms else None,
+                "spot_check": "ok" if res["valid"] else "MISMATCH: 8 output rows per rank differ from a direct evaluation",
+                "spmm_only_ms_per_step": res.get("spmm_only_ms"),
+                "spmm_only_edges_per_s": (2 * total / res["spmm_only_ms"] * 1e3) if res.get("spmm_only_ms") else None,
             },
             "roofline": {"bound": "hbm",
-                         "kernel": "spmm_csr_kernel (forward launch)" if mode != "features" else
+                         "kernel": "spmm_csr_kernel (forward launch)" if head != "features" else
                                    "spmm_csr_kernel (forward launch over this rank's column slab, timed in the "
                                    "exchange-free loop; the timed step cuts it into row-range launches between sends)",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": by, "avg_launch_ms": float(fwd_ms.mean()),
-                         "bwd_launch_ms": float(bwd_ms.mean()),
-                         "bwd_achieved_GBs": (by_bwd / (kernel_bwd_ms * 1e-3) / 1e9) if kernel_bwd_ms
-                         else (by_bwd / (bwd_ms.mean() * 1e-3) / 1e9 if mode == "none" else None),
-                         "bwd_kernel_ms": kernel_bwd_ms,
-                         "exchange_ms": float(xch_ms.mean()) if (xch_ms is not None and mode == "features"
-                                                                   and args.no_overlap) else None,
-                         "bwd_includes_exchange": bool(mode == "features" and not args.no_overlap),
+                         "traffic_source": traffic_src, "spmm_source_sha16": source_sha(),
+                         "algorithmic_bytes_per_launch": res["fwd_bytes"], "avg_launch_ms": res["fwd_ms"],
+                         "bwd_launch_ms": res["bwd_ms"],
+                         "bwd_achieved_GBs": res["bwd_bytes"] / (res["bwd_ms"] * 1e-3) / 1e9
+                         if (head != "rows") else None,
+                         "step_bwd_ms_including_exchange": res.get("step_bwd_ms"),
+                         "exchange_ms": res.get("exchange_ms"),
                          "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (one "
                                  "launch covering its 128-column slabs); it can exceed the ~6.3 TB/s of a plain HBM copy "
                                  "because slabs of the source table are partly served from the 256 MiB Infinity Cache, "
                                  "whose hits the fabric-side FETCH_SIZE counter (traffic) still counts"},
         }
+        if "rows" in results and head != "rows":      # the north star's scheme, same graph shape, next to the headline
+            rr = results["rows"]
+            out["rows_scheme"] = {
+                "sharding": f"head-row ranges x{world}, replicated table, gradient all-reduce",
+                "value": 2 * rr["total_entries"] * args.steps / rr["elapsed"], "unit": "edges/s",
+                "ms_per_step": rr["elapsed"] / args.steps * 1e3, "steps": args.steps,
+                "fwd_launch_ms": rr["fwd_ms"], "bwd_ms_including_all_reduce": rr["bwd_ms"],
+                "fwd_frac_of_hbm_roofline": rr["fwd_bytes"] / (rr["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "exchange": rr["exchange"],
+                "spot_check": "ok" if rr["valid"] else "MISMATCH"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, val, n_glob, d, 2022)
+            out["cpu_baseline"] = cpu_baseline(g_own, res["val"], n_glob, d, 2022)
         if world == 1 and not args.no_extra:
-            del side, grad_side, grad_table, shard, ent
+            results.clear()
+            del res
+            torch.cuda.empty_cache()
             out["extra"] = whole_path_timings(h, t, r, n_glob, d, dev)
         print(json.dumps(out))
     if world > 1:

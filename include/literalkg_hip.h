@@ -93,7 +93,10 @@ int lkg_laplacian_f32(int64_t n_entities, int64_t n_raw, int64_t nnz, const int3
  * K3/K4  neighbour aggregation  out[i,:] = sum_{j in row i} val[j] * x[col[j],:]
  * Replaces torch.matmul(A_in, ego) (model.py:106); called with the CSC arrays
  * it is the backward A^T grad.  Rows without entries are written as zeros.
- * rowptr is int32[n_rows+1] holding offsets into col/val; x has >= max(col)+1 rows.
+ * rowptr is int32[n_rows+1] holding offsets into col/val; x has >= max(col)+1 rows -- or is a SHIFTED view
+ * (x - offset*ldx) that covers at least every col value stored in the entries rowptr[0]..rowptr[n_rows] of THIS call
+ * (a row-range shard that holds only its own rows of x): the kernels never gather through an entry outside that range.
+ * Rows without entries come out as exact zeros whatever x holds.  The grid is limited to 2^32 threads.
  * long_rows (nullable, device int32[n_long]): the rows (relative to rowptr) holding more than
  * long_thresh entries; each of them gets a whole workgroup instead of one wave so that a skewed
  * degree distribution does not leave one wave as the tail of the launch.  The list must contain
@@ -131,8 +134,9 @@ int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowpt
  * (then rel is indexed by entry, and rel_first / dup_* / nnz are ignored).  With eptr: rel_first
  * int32[nnz] holds rel[eptr[j]] per entry; dup_entries int32[n_dup] lists the entries covering more than
  * one raw edge and dup_rows their head rows (relative to row_offset); a pre-pass adds their further
- * relations' terms so that the main kernel's hot loop never chases eptr -> rel; nnz = entries in val_out
- * (the rows' entry range must start at 0, i.e. val_out is cleared from its first element).  logits_out (nullable) receives the merged
+ * relations' terms so that the main kernel's hot loop never chases eptr -> rel; [entry_lo, entry_hi) =
+ * rowptr[0] .. rowptr[n_rows] (host-known) is the entry range this call refreshes: only those elements of
+ * val_out are cleared and rewritten, the rest is left untouched.  logits_out (nullable) receives the merged
  * pre-softmax logits, val_out the attention values, both float[nnz].
  * row_offset: rowptr holds n_rows+1 offsets for head rows row_offset..row_offset+n_rows
  * (a row-range shard of a larger graph; ent always holds the full table).
@@ -140,8 +144,8 @@ int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowpt
 int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
                          const int32_t *col, const int32_t *eptr, const int32_t *rel,
                          const int32_t *rel_first, const int32_t *dup_entries,
-                         const int32_t *dup_rows, int32_t n_dup, int64_t nnz, const float *ent,
-                         int64_t ld_ent, const float *relemb, int64_t ld_rel,
+                         const int32_t *dup_rows, int32_t n_dup, int64_t entry_lo, int64_t entry_hi,
+                         const float *ent, int64_t ld_ent, const float *relemb, int64_t ld_rel,
                          float *val_out, float *logits_out, const int32_t *long_rows, int32_t n_long,
                          int32_t long_thresh, void *stream);
 
@@ -178,9 +182,12 @@ int lkg_transe_score_bwd_f32(int64_t batch, int32_t dim, const float *emb, int64
  * gathered in that order, and ONE grouped MFMA GEMM applies W_r per relation segment.
  *
  * lkg_group_by_key_i64: perm int32[n] lists input positions in key order (stable), seg int32[n_keys+1]
- * the first position of each key.  Keys outside [0, n_keys) are clamped.                           */
+ * the first position of each key.  n_bad (nullable, device int32[1]) receives the number of keys outside
+ * [0, n_keys): the reference's gat_trans_M[r] raises IndexError on such a batch, so callers must treat n_bad > 0 as
+ * an error (ops.py checks it without a host sync, one call later); the kernel itself groups such a key with the
+ * nearest valid one only to keep the launches queued behind it in bounds.                           */
 int lkg_group_by_key_i64(int64_t n, int32_t n_keys, const int64_t *keys, int32_t *perm, int32_t *seg,
-                         void *stream);
+                         int32_t *n_bad, void *stream);
 /* dst[i,:] = src[idx[perm[i]],:]   (idx and/or perm may be NULL = identity)                         */
 int lkg_gather_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
                         const int32_t *perm, float *dst, int64_t ldd, void *stream);
@@ -194,10 +201,11 @@ int lkg_gather_i64(int64_t n, const int64_t *src, const int32_t *perm, int64_t *
  * DataLoader.generate_kg_batch (dataloader.py:249-330): for each of the n_groups heads one positive
  * (relation, tail) drawn uniformly from the head's triples and neg_rate negative tails drawn like
  * random.choice(training_tails), rejecting (tail, relation) positives of the head and repeats inside the
- * group; h / r / pos_t are repeated neg_rate times.  Outputs are int64[n_groups * neg_rate]; heads must
- * have at least one triple.  Counter-based RNG: the batch is a pure function of (seed, heads).        */
+ * group; h / r / pos_t are repeated neg_rate times.  Outputs are int64[n_groups * neg_rate].  A head outside
+ * [0, n_entities) or without a triple (kg_dict[h] raises KeyError in the reference) yields a sentinel group:
+ * r = pos_t = neg_t = -1, nothing is drawn.  Counter-based RNG: the batch is a pure function of (seed, heads).  */
 int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t seed, const int64_t *heads,
-                        const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                        int64_t n_entities, const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
                         int64_t nnz, int64_t n_raw, int64_t *out_h, int64_t *out_r, int64_t *out_pos_t,
                         int64_t *out_neg_t, void *stream);
 

@@ -21,17 +21,17 @@ PROTOTYPES = {
     "lkg_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp],
     "lkg_csr_extract_rows": [i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_spmm_csr_scatter_bwd_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp],
-    "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, i64, vp, i64, vp, vp, vp, i32,
-                             i32, vp],
+    "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, vp, vp,
+                             i32, i32, vp],
     "lkg_permute_f32": [i64, vp, vp, vp, vp],
     "lkg_transe_score_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_loss_reduce_f32": [i64, vp, vp, f32, vp, vp],
     "lkg_transe_score_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp, i64, vp],
-    "lkg_group_by_key_i64": [i64, i32, vp, vp, vp, vp],
+    "lkg_group_by_key_i64": [i64, i32, vp, vp, vp, vp, vp],
     "lkg_gather_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
     "lkg_scatter_add_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
     "lkg_gather_i64": [i64, vp, vp, vp, vp],
-    "lkg_sample_kg_batch": [i64, i32, u64, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp],
+    "lkg_sample_kg_batch": [i64, i32, u64, vp, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp],
     "lkg_grouped_gemm_f32": [i32, i32, vp, i64, i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, i64, f32, vp, i64,
                              i64, vp],
     "lkg_dense_score_fwd_f32": [i64, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],

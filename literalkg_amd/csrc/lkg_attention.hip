@@ -226,7 +226,7 @@ struct EsArgs {
     int nchunk;
     const int *rowptr, *col, *eptr, *rel, *rel_first, *dup_entries, *dup_rows;
     int n_dup;
-    int64_t nnz;
+    int64_t entry_lo, entry_hi;
     const float *ent;
     int64_t ld_ent;
     const float *relemb;
@@ -239,7 +239,8 @@ struct EsArgs {
 template <typename V, int LPE, int CPL, int U, bool DUPS>
 int launch2(const EsArgs &a, hipStream_t s) {
     if constexpr (DUPS) {
-        if (hipMemsetAsync(a.val_out, 0, sizeof(float) * a.nnz, s) != hipSuccess) {
+        // only THIS call's entries: a row-range refresh into an existing value array leaves the other rows alone
+        if (hipMemsetAsync(a.val_out + a.entry_lo, 0, sizeof(float) * (a.entry_hi - a.entry_lo), s) != hipSuccess) {
             lkg_set_error("lkg_edge_softmax_f32: hipMemsetAsync failed");
             return LKG_ERR_HIP;
         }
@@ -283,7 +284,8 @@ int dispatch(const EsArgs &a, hipStream_t s) {
 extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
                                     const int32_t *col, const int32_t *eptr, const int32_t *rel,
                                     const int32_t *rel_first, const int32_t *dup_entries, const int32_t *dup_rows,
-                                    int32_t n_dup, int64_t nnz, const float *ent, int64_t ld_ent,
+                                    int32_t n_dup, int64_t entry_lo, int64_t entry_hi, const float *ent,
+                                    int64_t ld_ent,
                                     const float *relemb, int64_t ld_rel, float *val_out, float *logits_out,
                                     const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_offset >= 0, "lkg_edge_softmax_f32: bad row range");
@@ -292,11 +294,12 @@ extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t 
                 "lkg_edge_softmax_f32: long-row list needs a pointer and a threshold >= 64");
     if (n_rows == 0) return LKG_OK;
     LKG_REQUIRE(rowptr && col && rel && ent && relemb && val_out, "lkg_edge_softmax_f32: null pointer");
-    LKG_REQUIRE(!eptr || (rel_first && nnz > 0 && n_dup >= 0 && (n_dup == 0 || (dup_entries && dup_rows))),
-                "lkg_edge_softmax_f32: eptr needs rel_first, nnz and the duplicate-entry list");
+    LKG_REQUIRE(!eptr || (rel_first && entry_lo >= 0 && entry_hi >= entry_lo && n_dup >= 0 &&
+                          (n_dup == 0 || (dup_entries && dup_rows))),
+                "lkg_edge_softmax_f32: eptr needs rel_first, the entry range and the duplicate-entry list");
     const bool vec = (d % 4 == 0) && (ld_ent % 4 == 0) && (ld_rel % 4 == 0) && lkg_aligned16(ent) && lkg_aligned16(relemb);
     EsArgs a{n_rows, row_offset, vec ? d / 4 : d, rowptr, col, eptr, rel, rel_first, dup_entries, dup_rows, n_dup,
-             nnz, ent, ld_ent, relemb, ld_rel,
+             entry_lo, entry_hi, ent, ld_ent, relemb, ld_rel,
              val_out, logits_out, long_rows, n_long, long_thresh};
     hipStream_t s = (hipStream_t)stream;
     return vec ? dispatch<float4>(a, s) : dispatch<float>(a, s);

@@ -12,19 +12,25 @@ constexpr int GB_WAVES = 16;
 // Deterministic (stable) counting sort of `keys` by value, one workgroup.
 //   perm[p] = position in the input of the p-th element in key order, seg[k] = first p of key k.
 __global__ __launch_bounds__(1024) void group_by_key_kernel(long n, int n_keys, const long *__restrict__ keys,
-                                                             int *__restrict__ perm, int *__restrict__ seg) {
-    extern __shared__ int sm[];   // [n_keys][GB_WAVES] running offsets
+                                                             int *__restrict__ perm, int *__restrict__ seg,
+                                                             int *__restrict__ n_bad) {
+    extern __shared__ int sm[];   // [n_keys][GB_WAVES] running offsets, then one counter of out-of-range keys
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    for (int i = t; i < n_keys * GB_WAVES; i += blockDim.x) sm[i] = 0;
+    for (int i = t; i < n_keys * GB_WAVES + 1; i += blockDim.x) sm[i] = 0;
     __syncthreads();
     const long chunk = ((n + GB_WAVES - 1) / GB_WAVES + 63) / 64 * 64;
     const long lo = min(n, (long)w * chunk), hi = min(n, lo + chunk);
     for (long i = lo + lane; i < hi; i += 64) {
-        const int k = (int)min(max(keys[i], 0L), (long)n_keys - 1);
+        const long key = keys[i];
+        // an out-of-range key is counted (the caller raises, like the reference's gat_trans_M[r] would) and grouped
+        // with the nearest valid key only so that this launch and the ones queued behind it stay in bounds
+        if (key < 0 || key >= n_keys) atomicAdd(&sm[n_keys * GB_WAVES], 1);
+        const int k = (int)min(max(key, 0L), (long)n_keys - 1);
         atomicAdd(&sm[k * GB_WAVES + w], 1);
     }
     __syncthreads();
     if (t == 0) {
+        if (n_bad) *n_bad = sm[n_keys * GB_WAVES];
         int run = 0;
         for (int k = 0; k < n_keys; ++k) {
             seg[k] = run;
@@ -99,12 +105,12 @@ __global__ void gather_i64_kernel(long n, const long *__restrict__ src, const in
 }  // namespace
 
 extern "C" int lkg_group_by_key_i64(int64_t n, int32_t n_keys, const int64_t *keys, int32_t *perm, int32_t *seg,
-                                    void *stream) {
+                                    int32_t *n_bad, void *stream) {
     LKG_REQUIRE(n >= 0 && n < INT32_MAX && n_keys >= 1, "lkg_group_by_key_i64: bad sizes");
     LKG_REQUIRE(n_keys <= 1024, "lkg_group_by_key_i64: at most 1024 distinct keys supported (got %d)", n_keys);
     LKG_REQUIRE(seg && (n == 0 || (keys && perm)), "lkg_group_by_key_i64: null pointer");
-    hipLaunchKernelGGL(group_by_key_kernel, dim3(1), dim3(1024), sizeof(int) * n_keys * GB_WAVES, (hipStream_t)stream,
-                       (long)n, n_keys, (const long *)keys, perm, seg);
+    hipLaunchKernelGGL(group_by_key_kernel, dim3(1), dim3(1024), sizeof(int) * (n_keys * GB_WAVES + 1),
+                       (hipStream_t)stream, (long)n, n_keys, (const long *)keys, perm, seg, n_bad);
     LKG_CHECK_LAUNCH("lkg_group_by_key_i64");
     return LKG_OK;
 }
@@ -184,7 +190,8 @@ __device__ __forceinline__ int entry_of_raw(const int *eptr, int nnz, int k) {
 }
 
 __global__ void sample_kg_batch_kernel(long n_groups, int neg_rate, unsigned long long seed,
-                                       const long *__restrict__ heads, const int *__restrict__ rowptr,
+                                       const long *__restrict__ heads, long n_ent,
+                                       const int *__restrict__ rowptr,
                                        const int *__restrict__ col, const int *__restrict__ eptr,
                                        const int *__restrict__ rel, int nnz, int n_raw, long *__restrict__ out_h,
                                        long *__restrict__ out_r, long *__restrict__ out_p, long *__restrict__ out_n) {
@@ -193,8 +200,15 @@ __global__ void sample_kg_batch_kernel(long n_groups, int neg_rate, unsigned lon
     if (g >= n_groups) return;
     Draw d{mix64(seed ^ (0xD1B54A32D192ED03ull * (unsigned long long)(g + 1))), 0u};
     const long h = heads[g];
-    const int j0 = rowptr[h], j1 = rowptr[h + 1];
+    const int j0 = (h >= 0 && h < n_ent) ? rowptr[h] : 0, j1 = (h >= 0 && h < n_ent) ? rowptr[h + 1] : 0;
     const int e0 = eptr ? eptr[j0] : j0, e1 = eptr ? eptr[j1] : j1;
+    if (e1 <= e0) {   // a head without triples (the reference's kg_dict[h] raises KeyError): sentinel group, no draw
+        for (int k = 0; k < neg_rate; ++k) {
+            out_h[g * neg_rate + k] = h;
+            out_r[g * neg_rate + k] = out_p[g * neg_rate + k] = out_n[g * neg_rate + k] = -1;
+        }
+        return;
+    }
     // positive: uniform over the head's raw triples
     const int ep = e0 + (int)d.below(e1 - e0);
     const long r = rel[ep];
@@ -227,17 +241,17 @@ __global__ void sample_kg_batch_kernel(long n_groups, int neg_rate, unsigned lon
 }  // namespace
 
 extern "C" int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t seed, const int64_t *heads,
-                                   const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
+                                   int64_t n_entities, const int32_t *rowptr, const int32_t *col, const int32_t *eptr, const int32_t *rel,
                                    int64_t nnz, int64_t n_raw, int64_t *out_h, int64_t *out_r, int64_t *out_pos_t,
                                    int64_t *out_neg_t, void *stream) {
-    LKG_REQUIRE(n_groups >= 0 && neg_rate >= 1 && nnz > 0 && n_raw >= nnz && n_raw < INT32_MAX,
+    LKG_REQUIRE(n_groups >= 0 && neg_rate >= 1 && n_entities > 0 && nnz > 0 && n_raw >= nnz && n_raw < INT32_MAX,
                 "lkg_sample_kg_batch: bad sizes");
     if (n_groups == 0) return LKG_OK;
     LKG_REQUIRE(heads && rowptr && col && rel && out_h && out_r && out_pos_t && out_neg_t,
                 "lkg_sample_kg_batch: null pointer");
     hipLaunchKernelGGL(sample_kg_batch_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0,
                        (hipStream_t)stream, (long)n_groups, neg_rate, (unsigned long long)seed, (const long *)heads,
-                       rowptr, col, eptr, rel, (int)nnz, (int)n_raw, (long *)out_h, (long *)out_r, (long *)out_pos_t,
+                       (long)n_entities, rowptr, col, eptr, rel, (int)nnz, (int)n_raw, (long *)out_h, (long *)out_r, (long *)out_pos_t,
                        (long *)out_neg_t);
     LKG_CHECK_LAUNCH("lkg_sample_kg_batch");
     return LKG_OK;

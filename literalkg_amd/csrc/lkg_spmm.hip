@@ -240,12 +240,18 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
     const bool mine = valid && !(n_long > 0 && len > long_thresh);
     if (!mine) len = 0;
     int maxlen = len;
+    // idle sub-groups (empty, skipped or out-of-range rows) gather, with weight 0, an entry of a LIVE row of this wave:
+    // always a valid entry of this launch's row range (x may be a shifted view that only covers those, x_row_offset)
+    int spare = len > 0 ? start : -1;
 #pragma unroll
-    for (int m = LPE; m < 64; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m, 64));
+    for (int m = LPE; m < 64; m <<= 1) {
+        maxlen = max(maxlen, __shfl_xor(maxlen, m, 64));
+        spare = max(spare, __shfl_xor(spare, m, 64));
+    }
     V acc = ops::zero();
     for (int k = 0; k < maxlen; k += LPE) {
         const int j = k + sl;
-        const int jc = len > 0 ? start + min(j, len - 1) : 0;   // the loop only runs when the CSR has entries
+        const int jc = len > 0 ? start + min(j, len - 1) : spare;   // maxlen > 0: some row of the wave has entries
         const int c = col[jc];
         const float v = j < len ? val[jc] : 0.f;
         const int mcnt = min(LPE, maxlen - k);                    // wave-uniform
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
         }
     }
     if (mine && (FULL || sl < nchunk)) {
+        if (len == 0) acc = ops::zero();   // an empty row is exactly 0 (0 * Inf/NaN of the spare gathers must not leak)
         if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[sl]);
         reinterpret_cast<V *>(out + (long)row * ldo)[sl] = acc;
     }
@@ -279,6 +286,7 @@ int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col
                    int n_long, int long_thresh, hipStream_t s) {
     constexpr int rows_per_block = 4 * (64 / LPE);
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block + n_long;
+    LKG_REQUIRE(blocks * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)", (long long)blocks);
     hipLaunchKernelGGL((spmm_csr_grouped_kernel<V, LPE, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s,
                        (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
                        long_rows, n_long, long_thresh);
@@ -291,7 +299,8 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
            int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
            int long_thresh, int n_slabs, int slab_cols, hipStream_t s) {
     const int64_t blocks = (n_rows + 3) / 4 + n_long;
-    LKG_REQUIRE(blocks * n_slabs < INT32_MAX, "lkg_spmm_csr_f32: grid too large");
+    LKG_REQUIRE(blocks * n_slabs * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)",
+                (long long)(blocks * n_slabs));
     hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0, s,
                        (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
                        long_rows, n_long, long_thresh, (int)blocks, slab_cols);

@@ -57,6 +57,42 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+# ----------------------------------------------------------------------------- deferred device-side checks
+class _Deferred:
+    """Error conditions a kernel detects on the device (an id out of range) without stalling the step on a host
+    sync: the kernel writes a counter, the counter is copied to pinned host memory behind it, and the NEXT op that
+    polls (or ``check_deferred_errors()``, which waits) raises -- the way an asynchronous device-side assert of the
+    reference's ``gat_trans_M[r]`` would surface one call late."""
+    pending = []
+
+    @classmethod
+    def watch(cls, counter: torch.Tensor, exc, message: str):
+        host = torch.empty(counter.shape, dtype=counter.dtype, pin_memory=True)
+        host.copy_(counter, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cls.pending.append((ev, host, exc, message))
+
+    @classmethod
+    def poll(cls, wait: bool = False):
+        keep, err = [], None
+        for ev, host, exc, message in cls.pending:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, exc, message))
+            elif int(host.sum()) != 0 and err is None:
+                err = exc(message.format(n=int(host.sum())))
+        cls.pending = keep
+        if err is not None:
+            raise err
+
+
+def check_deferred_errors():
+    """Wait for the device and raise any pending deferred error (call before trusting a step's results)."""
+    _Deferred.poll(wait=True)
+
+
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
@@ -127,8 +163,10 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
             keep = (dr >= row_lo) & (dr < row_hi)
             de, dr = de[keep].contiguous(), (dr[keep] - row_lo).contiguous()
         dup = (N.ptr(de), N.ptr(dr), de.numel())
+    rp = g.host("rowptr")
     N.call("lkg_edge_softmax_f32", row_hi - row_lo, row_lo, ent.shape[1], g.rowptr.data_ptr() + 4 * row_lo,
-           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, g.nnz, N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
+           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, int(rp[row_lo]), int(rp[row_hi]),
+           N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
            N.ptr(logits), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
            _stream())
     return val, logits
@@ -493,9 +531,15 @@ class _TransRLoss(Function):
         h, r, pt, nt = _i64(h), _i64(r), _i64(pt), _i64(nt)
         b = h.numel()
         dev = emb.device
+        _Deferred.poll()
         perm = torch.empty(b, dtype=torch.int32, device=dev)
-        seg = torch.empty(n_rel + 1, dtype=torch.int32, device=dev)
-        N.call("lkg_group_by_key_i64", b, n_rel, N.ptr(r), N.ptr(perm), N.ptr(seg), _stream())
+        seg = torch.empty(n_rel + 2, dtype=torch.int32, device=dev)      # [n_rel + 1] offsets + the bad-key counter
+        N.call("lkg_group_by_key_i64", b, n_rel, N.ptr(r), N.ptr(perm), N.ptr(seg), seg.data_ptr() + 4 * (n_rel + 1),
+               _stream())
+        _Deferred.watch(seg[n_rel + 1:], IndexError,
+                        "pre_training batch holds {n} relation id(s) outside [0, n_relations) (gat_trans_M[r], "
+                        "model.py:372)")
+        seg = seg[:n_rel + 1]
         rs = torch.empty_like(r)
         N.call("lkg_gather_i64", b, N.ptr(r), N.ptr(perm), N.ptr(rs), _stream())
         x = torch.empty((3, b, c), dtype=torch.float32, device=dev)      # gathered rows, relation order

@@ -28,6 +28,14 @@ class KGBatchSampler:
         (epoch_sampling_data_dict, main_pretraining.py:93-96)."""
         ops._need_gpu(self.graph.rowptr)
         pool = self.heads if heads is None else heads.long()
+        if heads is not None and pool.numel():
+            # caller-supplied heads: the reference's kg_dict[h] raises KeyError for an entity without triples
+            inside = (pool >= 0) & (pool < self.graph.n)
+            deg = self.graph.rowptr[1:] - self.graph.rowptr[:-1]
+            ok = inside & (deg[pool.clamp(0, self.graph.n - 1)] > 0)
+            if not bool(ok.all()):
+                raise KeyError(f"sample(heads=...): {int((~ok).sum())} head id(s) outside [0, {self.graph.n}) or "
+                               f"without a triple, e.g. {int(pool[~ok][0])}")
         groups = int(batch_size / self.neg_rate)                     # dataloader.py:285
         if groups <= pool.numel():                                   # random.sample: without replacement
             chosen = pool[torch.randperm(pool.numel(), device=pool.device)[:groups]]
@@ -37,7 +45,7 @@ class KGBatchSampler:
         seed = ops.new_seed() if seed is None else seed
         g = self.graph
         out = torch.empty((4, groups * self.neg_rate), dtype=torch.int64, device=chosen.device)
-        N.call("lkg_sample_kg_batch", groups, self.neg_rate, int(seed), N.ptr(chosen), N.ptr(g.rowptr), N.ptr(g.col),
+        N.call("lkg_sample_kg_batch", groups, self.neg_rate, int(seed), N.ptr(chosen), g.n, N.ptr(g.rowptr), N.ptr(g.col),
                N.ptr(g.eptr), N.ptr(g.rel), g.nnz, g.n_raw, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]),
                N.ptr(out[3]), ops._stream())
         return out[0], out[1], out[2], out[3]

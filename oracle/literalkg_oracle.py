@@ -258,8 +258,27 @@ def triple_scores_transr(p: Params, gat: torch.Tensor, h, r, pos_t, neg_t):
     return pos, neg, (ph, r_e, pp, pn)
 
 
-def triple_loss_transr(p: Params, cfg, gat: torch.Tensor, h, r, pos_t, neg_t) -> torch.Tensor:
-    pos, neg, (ph, r_e, pp, pn) = triple_scores_transr(p, gat, h, r, pos_t, neg_t)
+def triple_scores_transr_by_relation(p: Params, gat: torch.Tensor, h, r, pos_t, neg_t):
+    """The same quantities for batches whose B x C x D gather of ``gat_trans_M[r]`` (model.py:372) does not fit in
+    memory (C5: 32 768 x 2048 x 512 fp32 = 137 GB): rows are projected relation by relation,
+    ``x @ gat_trans_M[k]`` for the rows with r == k -- row by row the product ``bmm`` forms.  Held to
+    ``triple_scores_transr`` on the fixtures by tests/test_oracle_golden.py."""
+    r_e = p["relation_embed.weight"][r]
+    m = p["gat_trans_M"]
+    ph, pp, pn = (torch.zeros(h.numel(), m.shape[2], dtype=gat.dtype) for _ in range(3))
+    for k in torch.unique(r).tolist():
+        sel = torch.nonzero(r == k, as_tuple=True)[0]
+        ph = ph.index_add(0, sel, gat[h[sel]] @ m[k])
+        pp = pp.index_add(0, sel, gat[pos_t[sel]] @ m[k])
+        pn = pn.index_add(0, sel, gat[neg_t[sel]] @ m[k])
+    pos = (ph + r_e - pp).square().sum(dim=1)
+    neg = (ph + r_e - pn).square().sum(dim=1)
+    return pos, neg, (ph, r_e, pp, pn)
+
+
+def triple_loss_transr(p: Params, cfg, gat: torch.Tensor, h, r, pos_t, neg_t, by_relation: bool = False) -> torch.Tensor:
+    scores = triple_scores_transr_by_relation if by_relation else triple_scores_transr
+    pos, neg, (ph, r_e, pp, pn) = scores(p, gat, h, r, pos_t, neg_t)
     rank = (-F.logsigmoid(neg - pos)).mean()
     reg = l2_loss_mean(ph) + l2_loss_mean(r_e) + l2_loss_mean(pp) + l2_loss_mean(pn)
     return rank + cfg.kg_l2loss_lambda * reg
@@ -309,10 +328,10 @@ def predict_links(cfg, gat: torch.Tensor, head_ids, tail_ids) -> torch.Tensor:
 # whole modes, for end-to-end parity and for the timed CPU baseline
 # --------------------------------------------------------------------------
 def pre_training_loss(p: Params, cfg, a_in, h, r, pos_t, neg_t, num=None, txt=None,
-                      form: str = "transr", training: bool = False) -> torch.Tensor:
+                      form: str = "transr", training: bool = False, by_relation: bool = False) -> torch.Tensor:
     gat = gat_embeddings(p, cfg, a_in, num, txt, training)
     if form == "transr":
-        return triple_loss_transr(p, cfg, gat, h, r, pos_t, neg_t)
+        return triple_loss_transr(p, cfg, gat, h, r, pos_t, neg_t, by_relation)
     return triple_loss_transe(p, cfg, gat, h, r, pos_t, neg_t)
 
 

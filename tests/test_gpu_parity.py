@@ -939,6 +939,14 @@ def test_update_att_structure_cache_follows_content(L, O, gpu_device):
     t.copy_(t2)                                                    # same tensor object and address, new content
     m(h, t, r, rel, device=gpu_device, mode="update_att")
     assert m._triple_graph is not g1
+    # two edges swap their tails: every per-list sum stays the same, only an exact compare sees the change
+    g2 = m._triple_graph
+    i, j = 0, int(torch.nonzero((h != h[0]) & (t != t[0]))[0])
+    t3 = t.clone()
+    t3[i], t3[j] = t[j], t[i]
+    t.copy_(t3)
+    m(h, t, r, rel, device=gpu_device, mode="update_att")
+    assert m._triple_graph is not g2
     p = golden_params(gd)
     want = O.attention_refresh(n, p["entity_embed.weight"], p["relation_embed.weight"], h.cpu(), t.cpu(), r.cpu()).coalesce()
     assert torch.equal(m.A_in.data.indices().cpu(), want.indices())

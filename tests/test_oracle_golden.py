@@ -54,6 +54,12 @@ def test_encoder_loss_grads(name):
     np.testing.assert_allclose(pos.detach().numpy(), g["pos"], rtol=TOL, atol=TOL)
     np.testing.assert_allclose(neg.detach().numpy(), g["neg"], rtol=TOL, atol=TOL)
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=TOL)
+    if form == "transr":   # the relation-by-relation form the big-batch GPU tests use is the same function
+        pos2, neg2, _ = O.triple_scores_transr_by_relation(p, gat, bh, br, bp, bn)
+        np.testing.assert_allclose(pos2.detach().numpy(), g["pos"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(neg2.detach().numpy(), g["neg"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(O.triple_loss_transr(p, cfg, gat, bh, br, bp, bn, by_relation=True).item(),
+                                   g["loss"], rtol=TOL)
     loss.backward()
     checked = 0
     for k, v in g.items():

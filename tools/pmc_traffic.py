@@ -4,7 +4,7 @@ the forward SpMM.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM se
 counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) read -> x2;
 WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Separate --pmc passes (TCC slots).
    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [gpurun_out/pmc_tcc] > profiles/rNN_pmc_traffic.json"""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 
 def per_dispatch(d, kernel="spmm_csr_kernel"):
     f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
@@ -31,7 +31,10 @@ write = per_dispatch(sys.argv[2])["WRITE_SIZE"]
 fwd_f, bwd_f = per_call(fetch)
 fwd_w, bwd_w = per_call(write)
 mean = lambda x: sum(x) / len(x)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {
+    # bench.py reports `traffic` only while lkg_spmm.hip still has this hash (the counters describe THAT kernel)
+    "spmm_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "literalkg_amd", "csrc", "lkg_spmm.hip"), "rb").read()).hexdigest()[:16],
     "kernel": f"spmm_csr_kernel<float4,32,1,4,true>, {SLABS} launch(es) per call (128-column slabs, slab-major)", "calls_sampled": len(fwd_f),
     "FETCH_SIZE_KiB_fwd": mean(fwd_f), "WRITE_SIZE_KiB_fwd": mean(fwd_w),
     "FETCH_SIZE_KiB_bwd": mean(bwd_f), "WRITE_SIZE_KiB_bwd": mean(bwd_w),
