@@ -244,16 +244,30 @@ int lkg_relu_batchnorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz
                                float *g_beta, void *stream);
 
 /* Scores on already-projected rows (TransR form, model.py:413-426): same outputs
- * as lkg_transe_score_fwd_f32 but ph/pp/pn are dense batch x dim matrices.       */
-int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,
+ * as lkg_transe_score_fwd_f32 but ph/pp/pn are dense matrices.
+ * rows_per_group = K >= 1: the batch is batch/K groups of K consecutive rows that share (h, r, t+) -- the layout
+ * DataLoader.generate_kg_batch produces (dataloader.py:318-330, each sampled head repeated neg_rate times).  Then
+ * ph / pp / r (and g_ph / g_pp in the backward) hold ONE row per group (batch/K rows), pn / g_pn one row per triple:
+ * the head and the positive tail are projected once per group instead of K times (2(2+K)/K B C D flops instead of
+ * the reference's 6 B C D).  K = 1 is the general batch.  pos / neg / reg / rank are per triple either way.    */
+int lkg_dense_score_fwd_f32(int64_t batch, int32_t rows_per_group, int32_t dim, const float *ph, const float *pp,
                             const float *pn, int64_t ld, const float *relemb, int64_t ld_rel,
                             const int64_t *r, float *pos, float *neg, float *reg, float *rank,
                             void *stream);
-int lkg_dense_score_bwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp,
+int lkg_dense_score_bwd_f32(int64_t batch, int32_t rows_per_group, int32_t dim, const float *ph, const float *pp,
                             const float *pn, int64_t ld, const float *relemb, int64_t ld_rel,
                             const int64_t *r, const float *pos, const float *neg, float lambda,
                             const float *g_loss, float *g_ph, float *g_pp, float *g_pn,
                             int64_t ldg, float *g_rel, int64_t ld_grel, void *stream);
+/* Helpers of the grouped form.  lkg_check_grouped_i64: *n_bad (device int32) = number of rows that differ from the
+ * first row of their group of rows_per_group in h, r or pos_t (0 = the batch has the layout above).
+ * lkg_expand_groups_i32: from the key order of the GROUPS (perm / seg of lkg_group_by_key_i64 over one key per group)
+ * the row order of the batch: perm_out[p*K + j] = perm[p]*K + j (int32[n_groups*K]), seg_out[s] = seg[s]*K
+ * (int32[n_seg]).                                                                                                 */
+int lkg_check_grouped_i64(int64_t n, int32_t rows_per_group, const int64_t *h, const int64_t *r,
+                          const int64_t *pos_t, int32_t *n_bad, void *stream);
+int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, int32_t n_seg, const int32_t *perm,
+                          const int32_t *seg, int32_t *perm_out, int32_t *seg_out, void *stream);
 
 /* K5  row-wise epilogue of an aggregation layer (model.py:111, 161, 305):
  *   a   = leaky_relu(z, slope)                    (z = Linear output, n x d)

@@ -102,7 +102,56 @@ __global__ void gather_i64_kernel(long n, const long *__restrict__ src, const in
         dst[i] = src[perm[i]];
 }
 
+// perm_out[p * k + j] = perm[p] * k + j, seg_out[s] = seg[s] * k: the row order of a batch of n groups x k rows whose
+// GROUPS were sorted by key (the negatives of a grouped TransR batch follow their group)
+__global__ void expand_groups_kernel(long n, int k, int n_seg, const int *__restrict__ perm, const int *__restrict__ seg,
+                                     int *__restrict__ perm_out, int *__restrict__ seg_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)n_seg) seg_out[i] = seg[i] * k;
+    if (i < n * k) perm_out[i] = perm[i / k] * k + (int)(i % k);
+}
+
+// mismatches of the a12 layout: rows j of group i that differ from the group's first row in h, r or t+
+__global__ void check_grouped_kernel(long n, int k, const long *__restrict__ h, const long *__restrict__ r,
+                                     const long *__restrict__ p, int *__restrict__ n_bad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const long f = i / k * k;
+        bad = h[i] != h[f] || r[i] != r[f] || p[i] != p[f];
+    }
+    const unsigned long long m = __ballot(bad);   // taken by all lanes, before the divergent add
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(n_bad, (int)__popcll(m));
+}
+
 }  // namespace
+
+extern "C" int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, int32_t n_seg, const int32_t *perm,
+                                     const int32_t *seg, int32_t *perm_out, int32_t *seg_out, void *stream) {
+    LKG_REQUIRE(n_groups >= 0 && rows_per_group >= 1 && n_seg >= 1 && n_groups * rows_per_group < INT32_MAX,
+                "lkg_expand_groups_i32: bad sizes");
+    LKG_REQUIRE(seg && seg_out && (n_groups == 0 || (perm && perm_out)), "lkg_expand_groups_i32: null pointer");
+    const int64_t n = std::max<int64_t>(n_groups * rows_per_group, n_seg);
+    hipLaunchKernelGGL(expand_groups_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n_groups, rows_per_group, n_seg, perm, seg, perm_out, seg_out);
+    LKG_CHECK_LAUNCH("lkg_expand_groups_i32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_check_grouped_i64(int64_t n, int32_t rows_per_group, const int64_t *h, const int64_t *r,
+                                     const int64_t *pos_t, int32_t *n_bad, void *stream) {
+    LKG_REQUIRE(n >= 0 && rows_per_group >= 1, "lkg_check_grouped_i64: bad sizes");
+    LKG_REQUIRE(n_bad && (n == 0 || (h && r && pos_t)), "lkg_check_grouped_i64: null pointer");
+    if (hipMemsetAsync(n_bad, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+        lkg_set_error("lkg_check_grouped_i64: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    if (n == 0) return LKG_OK;
+    hipLaunchKernelGGL(check_grouped_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n, rows_per_group, (const long *)h, (const long *)r, (const long *)pos_t, n_bad);
+    LKG_CHECK_LAUNCH("lkg_check_grouped_i64");
+    return LKG_OK;
+}
 
 extern "C" int lkg_group_by_key_i64(int64_t n, int32_t n_keys, const int64_t *keys, int32_t *perm, int32_t *seg,
                                     int32_t *n_bad, void *stream) {

@@ -66,21 +66,23 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(long batch, int dim, con
                                                          const long *__restrict__ h, const long *__restrict__ r,
                                                          const long *__restrict__ pt, const long *__restrict__ nt,
                                                          float *__restrict__ pos, float *__restrict__ neg,
-                                                         float *__restrict__ reg, float *__restrict__ rank) {
+                                                         float *__restrict__ reg, float *__restrict__ rank, int rpg) {
     const int lane = threadIdx.x & 63;
     const long t = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= batch) return;
     const float *eh, *ep, *en;
-    if constexpr (DENSE) {
-        eh = a + t * ld;
-        ep = b + t * ld;
+    long tr = t;
+    if constexpr (DENSE) {   // rpg consecutive rows share one projected head / positive tail / relation (a12 layout)
+        tr = t / rpg;
+        eh = a + tr * ld;
+        ep = b + tr * ld;
         en = c + t * ld;
     } else {
         eh = a + h[t] * ld;
         ep = a + pt[t] * ld;
         en = a + nt[t] * ld;
     }
-    const float *er = relemb + r[t] * ld_rel;
+    const float *er = relemb + r[tr] * ld_rel;
     float ps, ng, rg;
     score_row<VEC>(eh, ep, en, er, dim, lane, ps, ng, rg);
     if (lane == 0) {
@@ -178,6 +180,85 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(long batch, int dim, con
     }
 }
 
+// Backward on projected rows when RPG consecutive rows share (h, r, t+) (the a12 layout of generate_kg_batch,
+// dataloader.py:318-330): ph / pp / r / g_ph / g_pp hold ONE row per group.  One workgroup per group; its four waves
+// take interleaved rows, a lane owns JT columns of a 64*JT-column tile and keeps the group's sums in registers
+//   S = sum_k 2 (u_k dp_k + w_k dn_k)      P = sum_k -2 u_k dp_k
+// (g_ph = S + K lr ph, g_pp = P + K lr pp, g_rel[r] += S + K lr r: one atomic per group and column instead of one
+// per row); g_pn is written row by row.  The waves meet in LDS in a fixed order: deterministic apart from g_rel.
+template <int JT>
+__global__ __launch_bounds__(256) void score_bwd_grouped_kernel(long n_groups, int rpg, int dim,
+                                                                 const float *__restrict__ ph,
+                                                                 const float *__restrict__ pp,
+                                                                 const float *__restrict__ pn, long ld,
+                                                                 const float *__restrict__ relemb, long ld_rel,
+                                                                 const long *__restrict__ r,
+                                                                 const float *__restrict__ pos,
+                                                                 const float *__restrict__ neg, float lambda,
+                                                                 const float *__restrict__ g_loss,
+                                                                 float *__restrict__ g_ph, float *__restrict__ g_pp,
+                                                                 float *__restrict__ g_pn, long ldg,
+                                                                 float *__restrict__ g_rel, long ld_grel) {
+    __shared__ float red[2][4][JT][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long grp = blockIdx.x;
+    const long batch = n_groups * rpg;
+    const float g = g_loss[0];
+    const float inv_b = 1.f / (float)batch;
+    const float lr = g * lambda * inv_b;
+    const float *eh = ph + grp * ld, *ep = pp + grp * ld, *er = relemb + r[grp] * ld_rel;
+    for (int c0 = 0; c0 < dim; c0 += 64 * JT) {
+        float vh[JT], vp[JT], vr[JT], S[JT], P[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int c = c0 + lane + 64 * j;
+            const bool ok = c < dim;
+            vh[j] = ok ? eh[c] : 0.f;
+            vp[j] = ok ? ep[c] : 0.f;
+            vr[j] = ok ? er[c] : 0.f;
+            S[j] = P[j] = 0.f;
+        }
+        for (int k = w; k < rpg; k += 4) {
+            const long t = grp * rpg + k;
+            const float dp = g * sigmoidf_(pos[t] - neg[t]) * inv_b, dn = -dp;
+            const float *en = pn + t * ld;
+            float *gn = g_pn + t * ldg;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int c = c0 + lane + 64 * j;
+                if (c < dim) {
+                    const float vn = en[c];
+                    const float u = vh[j] + vr[j] - vp[j], q = vh[j] + vr[j] - vn;
+                    S[j] += 2.f * (u * dp + q * dn);
+                    P[j] += -2.f * u * dp;
+                    gn[c] = -2.f * q * dn + lr * vn;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            red[0][w][j][lane] = S[j];
+            red[1][w][j][lane] = P[j];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int c = c0 + lane + 64 * j;
+                if (c < dim) {
+                    const float s = (red[0][0][j][lane] + red[0][1][j][lane]) + (red[0][2][j][lane] + red[0][3][j][lane]);
+                    const float p = (red[1][0][j][lane] + red[1][1][j][lane]) + (red[1][2][j][lane] + red[1][3][j][lane]);
+                    const float klr = lr * (float)rpg;
+                    g_ph[grp * ldg + c] = s + klr * vh[j];
+                    g_pp[grp * ldg + c] = p + klr * vp[j];
+                    atomicAdd(g_rel + r[grp] * ld_grel + c, s + klr * vr[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // f1 fine-tuning head: dot-product BPR (model.py:316-348)
 __global__ __launch_bounds__(256) void dot_fwd_kernel(long batch, int dim, const float *__restrict__ emb, long ld,
                                                        const long *__restrict__ h, const long *__restrict__ pt,
@@ -247,19 +328,23 @@ extern "C" int lkg_transe_score_fwd_f32(int64_t batch, int32_t dim, const float 
     if (vec_ok(dim, ld_emb, ld_rel, emb, relemb))
         hipLaunchKernelGGL((score_fwd_kernel<true, false>), grid, block, 0, s, (long)batch, dim, emb, nullptr, nullptr,
                            (long)ld_emb, relemb, (long)ld_rel, (const long *)h, (const long *)r, (const long *)pos_t,
-                           (const long *)neg_t, pos, neg, reg, rank);
+                           (const long *)neg_t, pos, neg, reg, rank, 1);
     else
         hipLaunchKernelGGL((score_fwd_kernel<false, false>), grid, block, 0, s, (long)batch, dim, emb, nullptr,
                            nullptr, (long)ld_emb, relemb, (long)ld_rel, (const long *)h, (const long *)r,
-                           (const long *)pos_t, (const long *)neg_t, pos, neg, reg, rank);
+                           (const long *)pos_t, (const long *)neg_t, pos, neg, reg, rank, 1);
     LKG_CHECK_LAUNCH("lkg_transe_score_fwd_f32");
     return LKG_OK;
 }
 
-extern "C" int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp, const float *pn,
-                                       int64_t ld, const float *relemb, int64_t ld_rel, const int64_t *r, float *pos,
-                                       float *neg, float *reg, float *rank, void *stream) {
+extern "C" int lkg_dense_score_fwd_f32(int64_t batch, int32_t rows_per_group, int32_t dim, const float *ph,
+                                       const float *pp, const float *pn, int64_t ld, const float *relemb,
+                                       int64_t ld_rel, const int64_t *r, float *pos, float *neg, float *reg,
+                                       float *rank, void *stream) {
     LKG_REQUIRE(batch >= 0 && dim > 0 && ld >= dim && ld_rel >= dim, "lkg_dense_score_fwd_f32: bad sizes");
+    LKG_REQUIRE(rows_per_group >= 1 && batch % rows_per_group == 0,
+                "lkg_dense_score_fwd_f32: batch %lld is not a whole number of groups of %d rows", (long long)batch,
+                rows_per_group);
     if (batch == 0) return LKG_OK;
     LKG_REQUIRE(ph && pp && pn && relemb && r && pos && neg && reg && rank, "lkg_dense_score_fwd_f32: null pointer");
     const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
@@ -267,10 +352,12 @@ extern "C" int lkg_dense_score_fwd_f32(int64_t batch, int32_t dim, const float *
     const bool v = vec_ok(dim, ld, ld_rel, ph, relemb) && lkg_aligned16(pp) && lkg_aligned16(pn);
     if (v)
         hipLaunchKernelGGL((score_fwd_kernel<true, true>), grid, block, 0, s, (long)batch, dim, ph, pp, pn, (long)ld,
-                           relemb, (long)ld_rel, nullptr, (const long *)r, nullptr, nullptr, pos, neg, reg, rank);
+                           relemb, (long)ld_rel, nullptr, (const long *)r, nullptr, nullptr, pos, neg, reg, rank,
+                           rows_per_group);
     else
         hipLaunchKernelGGL((score_fwd_kernel<false, true>), grid, block, 0, s, (long)batch, dim, ph, pp, pn, (long)ld,
-                           relemb, (long)ld_rel, nullptr, (const long *)r, nullptr, nullptr, pos, neg, reg, rank);
+                           relemb, (long)ld_rel, nullptr, (const long *)r, nullptr, nullptr, pos, neg, reg, rank,
+                           rows_per_group);
     LKG_CHECK_LAUNCH("lkg_dense_score_fwd_f32");
     return LKG_OK;
 }
@@ -303,16 +390,34 @@ extern "C" int lkg_transe_score_bwd_f32(int64_t batch, int32_t dim, const float 
     return LKG_OK;
 }
 
-extern "C" int lkg_dense_score_bwd_f32(int64_t batch, int32_t dim, const float *ph, const float *pp, const float *pn,
-                                       int64_t ld, const float *relemb, int64_t ld_rel, const int64_t *r,
-                                       const float *pos, const float *neg, float lambda, const float *g_loss,
-                                       float *g_ph, float *g_pp, float *g_pn, int64_t ldg, float *g_rel,
-                                       int64_t ld_grel, void *stream) {
+extern "C" int lkg_dense_score_bwd_f32(int64_t batch, int32_t rows_per_group, int32_t dim, const float *ph,
+                                       const float *pp, const float *pn, int64_t ld, const float *relemb,
+                                       int64_t ld_rel, const int64_t *r, const float *pos, const float *neg,
+                                       float lambda, const float *g_loss, float *g_ph, float *g_pp, float *g_pn,
+                                       int64_t ldg, float *g_rel, int64_t ld_grel, void *stream) {
     LKG_REQUIRE(batch >= 0 && dim > 0 && ld >= dim && ld_rel >= dim && ldg >= dim && ld_grel >= dim,
                 "lkg_dense_score_bwd_f32: bad sizes");
+    LKG_REQUIRE(rows_per_group >= 1 && batch % rows_per_group == 0,
+                "lkg_dense_score_bwd_f32: batch %lld is not a whole number of groups of %d rows", (long long)batch,
+                rows_per_group);
     if (batch == 0) return LKG_OK;
     LKG_REQUIRE(ph && pp && pn && relemb && r && pos && neg && g_loss && g_ph && g_pp && g_pn && g_rel,
                 "lkg_dense_score_bwd_f32: null pointer");
+    if (rows_per_group > 1) {
+        const long n_groups = batch / rows_per_group;
+        if (dim <= 256)
+            hipLaunchKernelGGL((score_bwd_grouped_kernel<4>), dim3((unsigned)n_groups), dim3(256), 0,
+                               (hipStream_t)stream, n_groups, rows_per_group, dim, ph, pp, pn, (long)ld, relemb,
+                               (long)ld_rel, (const long *)r, pos, neg, lambda, g_loss, g_ph, g_pp, g_pn, (long)ldg,
+                               g_rel, (long)ld_grel);
+        else
+            hipLaunchKernelGGL((score_bwd_grouped_kernel<8>), dim3((unsigned)n_groups), dim3(256), 0,
+                               (hipStream_t)stream, n_groups, rows_per_group, dim, ph, pp, pn, (long)ld, relemb,
+                               (long)ld_rel, (const long *)r, pos, neg, lambda, g_loss, g_ph, g_pp, g_pn, (long)ldg,
+                               g_rel, (long)ld_grel);
+        LKG_CHECK_LAUNCH("lkg_dense_score_bwd_f32");
+        return LKG_OK;
+    }
     hipLaunchKernelGGL((score_bwd_kernel<true>), dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (long)batch, dim, ph, pp, pn, (long)ld, relemb, (long)ld_rel, nullptr, (const long *)r, nullptr,
                        nullptr, pos, neg, lambda, g_loss, g_ph, g_pp, g_pn, (long)ldg, g_rel, (long)ld_grel);

@@ -229,6 +229,7 @@ class LiteralKG(nn.Module):
         self.prune_to_batch = bool(getattr(args, "prune_to_batch", False))
         self.prune_max_fraction = 0.5     # frontier larger than this share of the entities: the dense path is cheaper
         self.gat_rows = None
+        self.group_reuse = True           # TransR: project (h, t+) once per group of pre_training_neg_rate rows
         self._att: Optional[AttentionCSR] = None
         self._att_key = None
         self._triple_graph = None
@@ -338,11 +339,18 @@ class LiteralKG(nn.Module):
 
     # ------------------------------------------------------------------ a8/a9 loss
     def calc_triplet_loss(self, h, r, pos_t, neg_t):
+        # generate_kg_batch repeats every sampled (h, r, t+) pre_training_neg_rate times (dataloader.py:318-330): such
+        # a batch projects h and t+ once per group.  Checked on the ids (any other batch takes the general path).
+        group = 1
+        if self.scoring == "transr" and self.group_reuse:
+            k = int(self.pre_training_neg_rate)
+            if ops.is_grouped_batch(h, r, pos_t, k):
+                group = k
         self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         keep = self.last_scores if not self.training else None
         if self.scoring == "transr":
             return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
-                                   self.kg_l2loss_lambda, keep)
+                                   self.kg_l2loss_lambda, keep, group)
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
                                self.kg_l2loss_lambda, keep)
 

@@ -329,8 +329,9 @@ def test_config_c5_transr_k256_b32768(ops, O, gpu_device):
     lam = 1e-3
     pg = [x.to(gpu_device).requires_grad_(True) for x in (emb, relemb, wm)]
     keep = {}
-    loss = ops.transr_loss(pg[0], pg[1], pg[2], bh.to(gpu_device), br.to(gpu_device), bp.to(gpu_device),
-                           bn.to(gpu_device), lam, keep)
+    dev_b = [x.to(gpu_device) for x in (bh, br, bp, bn)]
+    assert ops.is_grouped_batch(dev_b[0], dev_b[1], dev_b[2], k)      # h and t+ projected once per 256 rows
+    loss = ops.transr_loss(pg[0], pg[1], pg[2], *dev_b, lam, keep, k)
     loss.backward()
     pc = {"relation_embed.weight": relemb.clone().requires_grad_(True), "gat_trans_M": wm.clone().requires_grad_(True)}
     gat = emb.clone().requires_grad_(True)

@@ -407,6 +407,66 @@ def test_triple_losses(ops, O, gpu_device, form, c, dout, b):
         torch.testing.assert_close(pg["gat_trans_M"].grad.cpu(), pc["gat_trans_M"].grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("c,dout,groups,k", [(40, 24, 37, 3), (96, 64, 50, 7), (300, 256, 9, 64), (64, 520, 5, 2)])
+def test_transr_group_reuse_matches_oracle_and_general_path(ops, O, gpu_device, c, dout, groups, k):
+    """a12 layout (dataloader.py:318-330): K consecutive rows share (h, r, t+); h and t+ are then projected once per
+    group.  Same loss / scores / gradients as the oracle and as the general (ungrouped) evaluation of the same batch."""
+    from types import SimpleNamespace
+    from literalkg_amd.synth import make_batch
+    gen = torch.Generator().manual_seed(k)
+    n, n_rel = 500, 16
+    gat = torch.randn(n, c, generator=gen) * 0.4
+    p = {"relation_embed.weight": torch.randn(n_rel, dout, generator=gen) * 0.4,
+         "gat_trans_M": torch.randn(n_rel, c, dout, generator=gen) * 0.2}
+    bh, br, bp, bn = (torch.from_numpy(x) for x in make_batch(n, groups, k, seed=k))
+    cfg = SimpleNamespace(kg_l2loss_lambda=1e-3)
+    gc = gat.clone().requires_grad_(True)
+    pc = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    want = O.triple_loss_transr(pc, cfg, gc, bh, br, bp, bn)
+    want.backward()
+    pos_w, neg_w, _ = O.triple_scores_transr(p, gat, bh, br, bp, bn)
+    dev = [x.to(gpu_device) for x in (bh, br, bp, bn)]
+    assert ops.is_grouped_batch(dev[0], dev[1], dev[2], k)
+    assert not ops.is_grouped_batch(dev[0], dev[1], dev[2], k + 1)
+    broken = dev[2].clone()
+    broken[k - 1] = (broken[k - 1] + 1) % n
+    assert not ops.is_grouped_batch(dev[0], dev[1], broken, k)
+    grads = {}
+    for group in (k, 1):
+        gg = gat.clone().to(gpu_device).requires_grad_(True)
+        pg = {kk: v.clone().to(gpu_device).requires_grad_(True) for kk, v in p.items()}
+        keep = {}
+        got = ops.transr_loss(gg, pg["relation_embed.weight"], pg["gat_trans_M"], *dev[:1], dev[1], dev[2], dev[3],
+                              1e-3, keep, group)
+        got.backward()
+        assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+        torch.testing.assert_close(keep["pos"].cpu(), pos_w, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(keep["neg"].cpu(), neg_w, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(gg.grad.cpu(), gc.grad, rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(pg["relation_embed.weight"].grad.cpu(), pc["relation_embed.weight"].grad, rtol=1e-3,
+                                   atol=1e-6)
+        torch.testing.assert_close(pg["gat_trans_M"].grad.cpu(), pc["gat_trans_M"].grad, rtol=1e-3, atol=1e-6)
+        grads[group] = gg.grad
+    torch.testing.assert_close(grads[k], grads[1], rtol=1e-4, atol=1e-6)
+
+
+def test_out_of_range_relation_raises_one_call_later(ops, gpu_device):
+    """gat_trans_M[r] with r outside [0, n_relations) is an IndexError in the reference; here the kernel counts such
+    keys and the error surfaces without a host sync in the step: at the next op, or at check_deferred_errors()."""
+    gen = torch.Generator().manual_seed(0)
+    emb = (torch.randn(50, 16, generator=gen)).to(gpu_device)
+    rel = torch.randn(4, 8, generator=gen).to(gpu_device)
+    wm = torch.randn(4, 16, 8, generator=gen).to(gpu_device)
+    ids = [torch.randint(0, 50, (12,), generator=gen).to(gpu_device) for _ in range(3)]
+    r = torch.tensor([0, 1, 2, 3, 4, 1, 2, 3, 0, 1, 2, -1], device=gpu_device)
+    ops.transr_loss(emb, rel, wm, ids[0], r, ids[1], ids[2], 1e-3)
+    with pytest.raises(IndexError, match="2 relation id"):
+        ops.check_deferred_errors()
+    ops.check_deferred_errors()          # reported once; the library stays usable
+    ok = ops.transr_loss(emb, rel, wm, ids[0], r.clamp(0, 3), ids[1], ids[2], 1e-3)
+    assert torch.isfinite(ok)
+
+
 # ----------------------------------------------------------------------------- whole module vs golden
 def _build_model(L, gd, device, scoring):
     cfg = golden_cfg(gd)
@@ -632,6 +692,33 @@ def test_kg_batch_sampler_contract(L, gpu_device):
     # more groups than heads: sampling with replacement still fills the batch
     few = s.sample(k * 50, heads=torch.tensor([11, 12], device=gpu_device), seed=3)
     assert few[0].numel() == 50 * k and set(few[0].tolist()) <= {11, 12}
+    # caller-supplied heads without a triple / outside the id range: KeyError like kg_dict[h] (dataloader.py:291)
+    empty_head = int(np.flatnonzero(np.bincount(h, minlength=n) == 0)[0])
+    for bad in ([11, empty_head], [11, n], [-1]):
+        with pytest.raises(KeyError):
+            s.sample(k * 2, heads=torch.tensor(bad, device=gpu_device), seed=3)
+
+
+def test_attention_row_range_refresh_leaves_other_rows_alone(L, ops, gpu_device):
+    """A row-range refresh into an existing value array (out=) on a graph WITH duplicate (h,t) pairs: the entries of
+    the other rows keep their values (only this call's entry range is cleared for the duplicate pre-pass)."""
+    rng = np.random.default_rng(8)
+    n, d = 300, 64
+    h, t, r = rand_graph(rng, n, 4000, n_rel=6, long_rows=[(5, 400)])
+    extra = np.stack([h[:80], (r[:80] + 1) % 6, t[:80]], 1)
+    trip = np.unique(np.concatenate([np.stack([h, r, t], 1), extra]), axis=0)
+    g = L.KGStructure.from_triples(n, trip[:, 0].copy(), trip[:, 2].copy(), trip[:, 1].copy(), device=gpu_device)
+    assert g.has_dups
+    ent = torch.randn(n, d, device=gpu_device) * 0.3
+    rel = torch.randn(6, d, device=gpu_device) * 0.3
+    full, _ = ops.edge_softmax(g, ent, rel)
+    out = torch.full((g.nnz,), -7.0, device=gpu_device)
+    lo, hi = 100, 220
+    ops.edge_softmax(g, ent, rel, row_lo=lo, row_hi=hi, out=out)
+    rp = g.host("rowptr")
+    a, b = int(rp[lo]), int(rp[hi])
+    torch.testing.assert_close(out[a:b], full[a:b], rtol=1e-6, atol=1e-8)
+    assert float((out[:a] + 7.0).abs().max()) == 0.0 and float((out[b:] + 7.0).abs().max()) == 0.0
 
 
 # ----------------------------------------------------------------------------- full-size properties
