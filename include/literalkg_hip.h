@@ -66,6 +66,23 @@ int lkg_csr_build(int64_t n_entities, int64_t n_edges, const int64_t *h, const i
 int lkg_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr,
                       const int32_t *col, int32_t *t_rowptr, int32_t *t_col, int32_t *t_perm);
 
+/* The same two builds on the DEVICE (lkg_csr_device.hip): h / t / r and every output are device pointers, outputs bit
+ * for bit those of lkg_csr_build / lkg_csr_transpose (stable (head, tail) order, ties in input order; heads ascending
+ * inside every tail of the CSC).  A hand-written LSD radix sort (8-bit digits) over the key head * n_entities + tail;
+ * no allocation: `workspace` holds at least lkg_csr_*_device_workspace(...) bytes.  order is int32[n_edges] here.
+ * counts (device int64[2]): counts[0] = number of stored entries, counts[1] = number of triples with an id outside
+ * [0, n_entities) or a relation outside int32 (the host build rejects such input; callers must treat counts[1] > 0 as
+ * the same error -- the outputs are then unspecified but in bounds).  The caller reads counts after the stream has
+ * reached this point (one host sync per edge list) to size col / eptr.                                              */
+int64_t lkg_csr_build_device_workspace(int64_t n_entities, int64_t n_edges);
+int lkg_csr_build_device(int64_t n_entities, int64_t n_edges, const int64_t *h, const int64_t *t, const int64_t *r,
+                         int32_t *rowptr, int32_t *col, int32_t *eptr, int32_t *rel, int32_t *order,
+                         int64_t *counts, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t lkg_csr_transpose_device_workspace(int64_t n_cols, int64_t nnz);
+int lkg_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                             int32_t *t_rowptr, int32_t *t_col, int32_t *t_perm, void *workspace,
+                             int64_t workspace_bytes, void *stream);
+
 /* Cut [0, n_rows) into n_parts contiguous row ranges balanced by stored entries
  * (cuts only at row boundaries so a softmax row never straddles two GPUs,
  * SURVEY.md 8e).  cuts int64[n_parts+1].                                     */

@@ -14,6 +14,10 @@ PROTOTYPES = {
     "lkg_csr_build": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_csr_transpose": [i64, i64, i64, vp, vp, vp, vp, vp],
     "lkg_row_partition": [i64, vp, i32, vp],
+    "lkg_csr_build_device_workspace": [i64, i64],
+    "lkg_csr_build_device": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lkg_csr_transpose_device_workspace": [i64, i64],
+    "lkg_csr_transpose_device": [i64, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp],
     "lkg_triples_count": [C.c_char_p, vp],
     "lkg_triples_read": [C.c_char_p, i64, vp, vp, vp, vp],
     "lkg_triples_dedup": [i64, vp, vp, vp, vp, vp],
@@ -53,7 +57,8 @@ PROTOTYPES = {
     "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],
     "lkg_adam_step_f32": [i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp],
 }
-_RESTYPE = {"lkg_last_error": C.c_char_p}
+_RESTYPE = {"lkg_last_error": C.c_char_p, "lkg_csr_build_device_workspace": C.c_int64,
+            "lkg_csr_transpose_device_workspace": C.c_int64}
 
 
 class LkgError(RuntimeError):

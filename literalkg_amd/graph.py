@@ -1,16 +1,19 @@
 """KG structure in HBM: (head, tail)-sorted CSR with merged duplicate pairs + its CSC.
 
-Built once on the host by the C ABI (``lkg_csr_build`` / ``lkg_csr_transpose``) and kept on the
-device as int32 arrays.  It replaces the sparse COO ``A_in`` *pattern* of the reference
-(model.py:257-261, 462-468); the attention VALUES stay a flat fp32 array aligned with ``col``.
+Built once per edge list -- on the DEVICE when the structure lives on a GPU (``lkg_csr_build_device`` /
+``lkg_csr_transpose_device``: a hand-written radix sort, milliseconds at 10 M triples), on the host otherwise
+(``lkg_csr_build`` / ``lkg_csr_transpose``; CPU tests, gloo rehearsals); both give the same arrays bit for bit.
+It replaces the sparse COO ``A_in`` *pattern* of the reference (model.py:257-261, 462-468); the attention VALUES stay
+a flat fp32 array aligned with ``col``.
 
-Layout (E_raw raw triples, nnz <= E_raw stored entries, N entities):
-    rowptr  int32[N+1]   entries of head row h are rowptr[h]..rowptr[h+1]
-    col     int32[nnz]   tail of each entry, ascending inside a row  (== coalesced COO order)
-    eptr    int32[nnz+1] entry j covers sorted raw edges eptr[j]..eptr[j+1]   (None when nnz == E_raw)
-    rel     int32[E_raw] relation of each sorted raw edge
-    rel_first int32[nnz] relation of the first raw edge of each entry (only with eptr)
+Layout (E_raw raw triples, nnz <= E_raw stored entries, N entities), all int32:
+    rowptr  [N+1]   entries of head row h are rowptr[h]..rowptr[h+1]
+    col     [nnz]   tail of each entry, ascending inside a row  (== coalesced COO order)
+    eptr    [nnz+1] entry j covers sorted raw edges eptr[j]..eptr[j+1]   (None when nnz == E_raw)
+    rel     [E_raw] relation of each sorted raw edge
+    rel_first [nnz] relation of the first raw edge of each entry (only with eptr)
     t_rowptr/t_col/t_perm  the CSC: for tail t the heads pointing at it, and the CSR entry id of each
+Host mirrors (numpy) of any array are made on demand by ``host(name)`` and cached.
 """
 from __future__ import annotations
 
@@ -24,16 +27,19 @@ from . import _native as N
 
 LONG_ROW_THRESHOLD = 256   # rows above this get a whole workgroup in the SpMM (lkg_spmm_csr_f32)
 
+_ARRAYS = ("rowptr", "col", "eptr", "rel", "rel_first", "dup_entries", "dup_rows", "t_rowptr", "t_col", "t_perm")
+
 
 class KGStructure:
     def __init__(self):
         self.n = 0
         self.nnz = 0
         self.n_raw = 0
-        self.rowptr = self.col = self.eptr = self.rel = self.rel_first = self.dup_entries = self.dup_rows = None
-        self.t_rowptr = self.t_col = self.t_perm = None
-        self.order = None           # int64 host: sorted raw edge k is input edge order[k]
+        for k in _ARRAYS:
+            setattr(self, k, None)
+        self._order = None          # sorted raw edge k is input edge order[k] (device int32 or host int64)
         self.device = torch.device("cpu")
+        self._host = {}
         self._coo = None
         self._long = {}
 
@@ -41,6 +47,16 @@ class KGStructure:
     @classmethod
     def from_triples(cls, n_entities: int, h, t, r=None, device=None, with_transpose: bool = True) -> "KGStructure":
         """h, t, r: 1-D integer tensors / arrays of equal length (any device); r=None -> relation 0."""
+        device = torch.device(device if device is not None else "cpu")
+        e = int(h.shape[0])
+        if int(t.shape[0]) != e or (r is not None and int(r.shape[0]) != e):
+            raise ValueError("h, t, r must have equal lengths")
+        if device.type == "cuda":
+            return cls._build_device(int(n_entities), h, t, r, device, with_transpose)
+        return cls._build_host(int(n_entities), h, t, r, device, with_transpose)
+
+    @classmethod
+    def _build_host(cls, n, h, t, r, device, with_transpose):
         def host(x):
             if x is None:
                 return None
@@ -49,9 +65,6 @@ class KGStructure:
             return np.ascontiguousarray(x, dtype=np.int64)
         hh, tt, rr = host(h), host(t), host(r)
         e = int(hh.shape[0])
-        if tt.shape[0] != e or (rr is not None and rr.shape[0] != e):
-            raise ValueError("h, t, r must have equal lengths")
-        n = int(n_entities)
         rowptr = np.empty(n + 1, np.int32)
         col = np.empty(max(e, 1), np.int32)
         eptr = np.empty(e + 1, np.int32)
@@ -62,23 +75,71 @@ class KGStructure:
                N.ptr(rel), N.ptr(order), N.ptr(nnz))
         g = cls()
         g.n, g.nnz, g.n_raw = n, int(nnz[0]), e
-        g.order = order[:e]
-        dups = g.nnz != e
-        g._host = dict(rowptr=rowptr, col=col[:g.nnz], rel=rel[:e], eptr=None, rel_first=None, dup_entries=None,
-                       dup_rows=None)
-        if dups:   # stored entries covering several raw edges (the same (h,t) under several relations)
+        g._order = order[:e]
+        host_arrays = dict(rowptr=rowptr, col=col[:g.nnz], rel=rel[:e])
+        if g.nnz != e:   # stored entries covering several raw edges (the same (h,t) under several relations)
             ep = eptr[:g.nnz + 1]
             de = np.flatnonzero(np.diff(ep) > 1).astype(np.int32)
-            g._host.update(eptr=ep, rel_first=rel[:e][ep[:-1]], dup_entries=de,
-                           dup_rows=(np.searchsorted(rowptr, de, side="right") - 1).astype(np.int32))
+            host_arrays.update(eptr=ep, rel_first=rel[:e][ep[:-1]], dup_entries=de,
+                               dup_rows=(np.searchsorted(rowptr, de, side="right") - 1).astype(np.int32))
         if with_transpose:
             t_rowptr = np.empty(n + 1, np.int32)
             t_col = np.empty(max(g.nnz, 1), np.int32)
             t_perm = np.empty(max(g.nnz, 1), np.int32)
             N.call("lkg_csr_transpose", n, n, g.nnz, N.ptr(rowptr), N.ptr(col), N.ptr(t_rowptr), N.ptr(t_col),
                    N.ptr(t_perm))
-            g._host.update(t_rowptr=t_rowptr, t_col=t_col[:g.nnz], t_perm=t_perm[:g.nnz])
-        g.to(device if device is not None else "cpu")
+            host_arrays.update(t_rowptr=t_rowptr, t_col=t_col[:g.nnz], t_perm=t_perm[:g.nnz])
+        g._host = host_arrays
+        for k, v in host_arrays.items():
+            setattr(g, k, torch.from_numpy(v).to(device))
+        g.device = device
+        return g
+
+    @classmethod
+    def _build_device(cls, n, h, t, r, device, with_transpose):
+        def dev(x):
+            if x is None:
+                return None
+            x = torch.as_tensor(x)
+            return x.to(device=device, dtype=torch.int64).contiguous()
+        hh, tt, rr = dev(h), dev(t), dev(r)
+        e = int(hh.shape[0])
+        stream = torch.cuda.current_stream(device).cuda_stream
+        i32 = dict(dtype=torch.int32, device=device)
+        rowptr = torch.empty(n + 1, **i32)
+        col = torch.empty(max(e, 1), **i32)
+        eptr = torch.empty(e + 1, **i32)
+        rel = torch.empty(max(e, 1), **i32)
+        order = torch.empty(max(e, 1), **i32)
+        counts = torch.empty(2, dtype=torch.int64, device=device)
+        ws_bytes = N.load().lkg_csr_build_device_workspace(n, e)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            N.call("lkg_csr_build_device", n, e, N.ptr(hh), N.ptr(tt), N.ptr(rr), N.ptr(rowptr), N.ptr(col),
+                   N.ptr(eptr), N.ptr(rel), N.ptr(order), N.ptr(counts), N.ptr(ws), ws_bytes, stream)
+            nnz, n_bad = (int(x) for x in counts.tolist())          # the one host sync of a build
+            if n_bad:
+                raise N.LkgError(f"lkg_csr_build_device: {n_bad} triple(s) with an entity id outside [0, {n}) or a "
+                                 f"relation id outside int32")
+            g = cls()
+            g.n, g.nnz, g.n_raw, g.device = n, nnz, e, device
+            g._order = order[:e]
+            g.rowptr, g.col, g.rel = rowptr, col[:nnz], rel[:e]
+            if nnz != e:
+                ep = eptr[:nnz + 1]
+                de = torch.nonzero((ep[1:] - ep[:-1]) > 1, as_tuple=True)[0].int()
+                g.eptr, g.rel_first, g.dup_entries = ep, rel[ep[:-1].long()], de
+                g.dup_rows = (torch.searchsorted(rowptr, de, right=True) - 1).int()
+            if with_transpose:
+                t_rowptr = torch.empty(n + 1, **i32)
+                t_col = torch.empty(max(nnz, 1), **i32)
+                t_perm = torch.empty(max(nnz, 1), **i32)
+                ws_t = N.load().lkg_csr_transpose_device_workspace(n, nnz)
+                if ws_t > ws_bytes:
+                    ws = torch.empty(ws_t, dtype=torch.uint8, device=device)
+                N.call("lkg_csr_transpose_device", n, n, nnz, N.ptr(rowptr), N.ptr(col), N.ptr(t_rowptr),
+                       N.ptr(t_col), N.ptr(t_perm), N.ptr(ws), ws.numel(), stream)
+                g.t_rowptr, g.t_col, g.t_perm = t_rowptr, t_col[:nnz], t_perm[:nnz]
         return g
 
     @classmethod
@@ -94,10 +155,10 @@ class KGStructure:
 
     def to(self, device) -> "KGStructure":
         device = torch.device(device)
-        for k, v in self._host.items():
-            setattr(self, k, None if v is None else torch.from_numpy(v).to(device))
-        if "t_rowptr" not in self._host:
-            self.t_rowptr = self.t_col = self.t_perm = None
+        for k in _ARRAYS:
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.to(device))
         self.device = device
         self._coo = None
         self._long = {}
@@ -109,15 +170,22 @@ class KGStructure:
         hi = self.n if hi is None else hi
         key = (transposed, lo, hi)
         if key not in self._long:
-            rp = self._host["t_rowptr" if transposed else "rowptr"]
-            rows = np.flatnonzero(np.diff(rp[lo:hi + 1]) > LONG_ROW_THRESHOLD).astype(np.int32)
-            self._long[key] = torch.from_numpy(rows).to(self.device) if len(rows) else None
+            rp = self.t_rowptr if transposed else self.rowptr
+            rows = torch.nonzero((rp[lo + 1:hi + 1] - rp[lo:hi]) > LONG_ROW_THRESHOLD, as_tuple=True)[0].int()
+            self._long[key] = rows if rows.numel() else None
         return self._long[key]
 
     # ------------------------------------------------------------------ views
     @property
     def has_dups(self) -> bool:
         return self.eptr is not None
+
+    @property
+    def order(self) -> np.ndarray:
+        """int64 host array: sorted raw edge k is input edge order[k]."""
+        if isinstance(self._order, torch.Tensor):
+            self._order = self._order.cpu().numpy().astype(np.int64)
+        return self._order
 
     def entry_rows(self) -> torch.Tensor:
         """int64[nnz] head of every stored entry."""
@@ -133,8 +201,12 @@ class KGStructure:
     def row_cuts(self, n_parts: int) -> np.ndarray:
         """nnz-balanced contiguous head-row ranges."""
         cuts = np.empty(n_parts + 1, np.int64)
-        N.call("lkg_row_partition", self.n, N.ptr(self._host["rowptr"]), int(n_parts), N.ptr(cuts))
+        N.call("lkg_row_partition", self.n, N.ptr(self.host("rowptr")), int(n_parts), N.ptr(cuts))
         return cuts
 
     def host(self, name: str):
+        """numpy mirror of one of the arrays (None when the structure has no such array); copied once."""
+        if name not in self._host:
+            v = getattr(self, name)
+            self._host[name] = None if v is None else np.ascontiguousarray(v.cpu().numpy())
         return self._host[name]

@@ -163,9 +163,13 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
             keep = (dr >= row_lo) & (dr < row_hi)
             de, dr = de[keep].contiguous(), (dr[keep] - row_lo).contiguous()
         dup = (N.ptr(de), N.ptr(dr), de.numel())
-    rp = g.host("rowptr")
+    if row_lo == 0 and row_hi == g.n:
+        e_lo, e_hi = 0, g.nnz
+    else:
+        rp = g.host("rowptr")
+        e_lo, e_hi = int(rp[row_lo]), int(rp[row_hi])
     N.call("lkg_edge_softmax_f32", row_hi - row_lo, row_lo, ent.shape[1], g.rowptr.data_ptr() + 4 * row_lo,
-           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, int(rp[row_lo]), int(rp[row_hi]),
+           N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, e_lo, e_hi,
            N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
            N.ptr(logits), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
            _stream())

@@ -721,6 +721,65 @@ def test_attention_row_range_refresh_leaves_other_rows_alone(L, ops, gpu_device)
     assert float((out[:a] + 7.0).abs().max()) == 0.0 and float((out[b:] + 7.0).abs().max()) == 0.0
 
 
+# ----------------------------------------------------------------------------- device-side structure build
+@pytest.mark.parametrize("n,e,n_rel,dup", [(1, 1, 1, 0), (7, 40, 3, 10), (300, 5000, 6, 200), (5000, 2049, 4, 0),
+                                            (70000, 300000, 16, 3000), (2_000_000, 150_000, 5, 50)])
+def test_device_csr_build_is_bit_exact_with_the_host_build(L, gpu_device, n, e, n_rel, dup):
+    """lkg_csr_build_device / lkg_csr_transpose_device (radix sort + scans on the GPU) against lkg_csr_build /
+    lkg_csr_transpose (host): every array identical -- sorted order, merged duplicate pairs, tie order of the raw
+    edges (input order), CSC with ascending heads -- for device AND host inputs."""
+    rng = np.random.default_rng(n + e)
+    h = rng.integers(0, n, e)
+    t = rng.integers(0, n, e)
+    r = rng.integers(0, n_rel, e)
+    if n > 10:
+        h[: e // 5] = rng.integers(0, 3, e // 5)                  # a few very long rows (> 256 entries)
+    if dup:
+        src = rng.integers(0, e, dup)
+        h = np.concatenate([h, h[src], h[src[: dup // 2]]])       # repeated (h, t) pairs, some three times
+        t = np.concatenate([t, t[src], t[src[: dup // 2]]])
+        r = np.concatenate([r, (r[src] + 1) % n_rel, r[src[: dup // 2]]])
+    gh = L.KGStructure.from_triples(n, h, t, r, device="cpu")
+    for inputs in ((h, t, r), tuple(torch.from_numpy(x).to(gpu_device) for x in (h, t, r))):
+        gd = L.KGStructure.from_triples(n, *inputs, device=gpu_device)
+        assert (gd.n, gd.nnz, gd.n_raw) == (gh.n, gh.nnz, gh.n_raw)
+        for name in ("rowptr", "col", "eptr", "rel", "rel_first", "dup_entries", "dup_rows", "t_rowptr", "t_col",
+                     "t_perm"):
+            a, b = gd.host(name), gh.host(name)
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert a.dtype == b.dtype and np.array_equal(a, b), name
+        assert np.array_equal(gd.order, gh.order)
+    none = L.KGStructure.from_triples(5, np.zeros(0, np.int64), np.zeros(0, np.int64), None, device=gpu_device)
+    assert none.nnz == 0 and none.host("rowptr").tolist() == [0] * 6 and none.host("t_rowptr").tolist() == [0] * 6
+    bad_t = t.copy()
+    bad_t[0] = n
+    from literalkg_amd._native import LkgError
+    with pytest.raises(LkgError, match="outside"):
+        L.KGStructure.from_triples(n, h, bad_t, r, device=gpu_device)
+
+
+def test_device_csr_build_at_full_size_is_fast(L, gpu_device):
+    """1 M entities / 10 M triples: same arrays as the host build, and the build (what the first update_att of an
+    edge list pays) takes milliseconds, not a host sort."""
+    import time
+    from literalkg_amd.synth import make_kg
+    n = 1_000_000
+    h, t, r = make_kg(n, 10_000_000)
+    gh = L.KGStructure.from_triples(n, h, t, r, device="cpu")
+    dev = tuple(torch.from_numpy(x).to(gpu_device) for x in (h, t, r))
+    L.KGStructure.from_triples(n, *dev, device=gpu_device)           # warm-up (allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gd = L.KGStructure.from_triples(n, *dev, device=gpu_device)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    for name in ("rowptr", "col", "eptr", "rel", "t_rowptr", "t_col", "t_perm"):
+        assert np.array_equal(gd.host(name), gh.host(name)), name
+    assert ms < 50.0, f"device structure build took {ms:.1f} ms"
+    print(f"device CSR+CSC build, 10 M triples: {ms:.2f} ms")
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(L, ops, gpu_device):
     """BASELINE config shape (1M entities / 10M edges / D=256): size-independent properties."""
