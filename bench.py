@@ -190,6 +190,71 @@ def gate_timing(n, d, dev):
             "algorithmic_bytes": alg, "algorithmic_GBs": alg / ms / 1e6}
 
 
+def sharded_step_timings(world, rank, dev, n_glob, d, h_own, t_own, r_own, steps):
+    """N > 1 context numbers, outside the headline metric: the INTEGRATED multi-GPU pre_training step of
+    literalkg_amd/distributed.py (row-sharded module: 1 gcn layer, D=d, TransR, 2049 triples, fused Adam on each rank's
+    shard) under both aggregation exchange schemes, forward + backward + gradient sync + optimizer step."""
+    from types import SimpleNamespace
+    import literalkg_amd as L
+    from literalkg_amd.distributed import ShardedLiteralKG
+    from literalkg_amd.optim import Adam
+    from literalkg_amd.synth import make_batch
+    cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=d, relation_dim=d, scale_gat_dim=None,
+                          use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=1,
+                          conv_dim=d, mess_dropout=0.1, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
+                          pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=300,
+                          use_num_lit=False, use_txt_lit=False, milestone_score=0.5, n_mlp_layers=2, mlp_hidden_dim=64)
+    batch = [torch.from_numpy(a).to(dev) for a in make_batch(n_glob, 683, 3)]
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    out = {}
+    for scheme in ("rows", "features"):
+        torch.manual_seed(1234)                                  # the same replicated weights on every rank
+        full = L.LiteralKG(cfg, 1, 16)                           # weights only; the entity shard is drawn per rank
+        state = {k: v for k, v in full.state_dict().items() if k not in ("A_in", "entity_embed.weight")}
+        part_rows = -(-n_glob // world)
+        lo = min(n_glob, rank * part_rows)
+        rows = min(n_glob, lo + part_rows) - lo
+        from literalkg_amd.distributed import RowPartition, HipKernels
+        local = L.LiteralKG(cfg, rows, 16)
+        local.load_state_dict(state, strict=False)
+        local.to(dev)
+        model = ShardedLiteralKG(local, RowPartition(n_glob, rank, world), scheme, HipKernels())
+        if scheme == "features":                                 # replicated structure: every rank needs all triples
+            mine = torch.from_numpy(np.stack([h_own, t_own, r_own])).to(cdev).reshape(-1)
+            every = torch.empty(world * mine.numel(), dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(every, mine)
+            every = every.view(world, 3, -1)
+            hh, tt, rr = (every[:, i].reshape(-1).to(dev) for i in range(3))
+        else:
+            hh, tt, rr = (torch.from_numpy(a).to(dev) for a in (h_own, t_own, r_own))
+        model(hh, tt, rr, list(range(16)), device=dev, mode="update_att")
+        model.train()
+        opt = Adam(model.parameters(), lr=1e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = model(*batch, device=dev, mode="pre_training")
+            loss.backward()
+            model.sync_gradients()
+            opt.step()
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64).to(cdev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        out[scheme] = {"ms_per_step": float(el) / steps * 1e3, "steps": steps}
+        del model, opt, local
+        torch.cuda.empty_cache()
+    out["config"] = f"ShardedLiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, {n_glob} entities over {world} ranks"
+    return out
+
+
 def self_launch(args):
     """--gpus N > 1 without a torch.distributed environment: start the N workers as a CHILD process (nothing in this
     process has touched the GPU yet, and the child is a new program, not an exec of this one)."""
@@ -254,6 +319,8 @@ def main():
                          "headline `value`); 'rows' = head-row ranges + all-reduce of the entity-gradient table (the "
                          "scheme BASELINE.json's north star names); 'both' (default) times features for `value` and "
                          "rows next to it in `rows_scheme`")
+    ap.add_argument("--no-sharded-step", action="store_true",
+                    help="N>1: skip the context timing of the integrated multi-GPU pre_training step")
     ap.add_argument("--no-overlap", action="store_true",
                     help="features scheme: plain all-to-all after the SpMM instead of per-range sends behind it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -453,6 +520,22 @@ def main():
         results[scheme] = run_features() if scheme == "features" else run_rows()
         torch.cuda.empty_cache()
 
+    sharded_step = None
+    if world > 1 and not args.no_sharded_step:
+        # after the headline measurements; an ordinary error here is reported in the JSON and does not cost the run
+        # (every rank takes the same branch: the agreement below is a collective)
+        ok, why = 1.0, ""
+        try:
+            sharded_step = sharded_step_timings(world, rank, dev, n_glob, d, h, t, r, max(3, min(args.steps, 10)))
+        except LkgError as exc:
+            ok, why = 0.0, f"LkgError: {exc}"
+        except RuntimeError as exc:
+            ok, why = 0.0, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([ok], device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag) == 0.0:
+            sharded_step = {"error": (why or "failed on another rank")[:300]}
+
     if rank == 0:
         head = schemes[0]
         res = results[head]
@@ -516,6 +599,8 @@ def main():
                 "fwd_frac_of_hbm_roofline": rr["fwd_bytes"] / (rr["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "exchange": rr["exchange"],
                 "spot_check": "ok" if rr["valid"] else "MISMATCH"}
+        if sharded_step is not None:
+            out["sharded_pre_training_step"] = sharded_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g_own, res["val"], n_glob, d, 2022)
         if world == 1 and not args.no_extra:

@@ -211,6 +211,15 @@ int lkg_gather_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, con
 /* dst[idx[perm[i]],:] += src[i,:]  (f32 atomics; autograd of the row gathers model.py:382-384)     */
 int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
                              const int32_t *perm, float *dst, int64_t ldd, void *stream);
+/* Row-range forms for a table sharded by rows over the ranks of one node (literalkg_amd/distributed.py): this rank
+ * holds rows [row_lo, row_hi) and src / dst point at row row_lo.
+ *   gather : dst[i,:] = src[idx[i] - row_lo,:] when idx[i] is in the range, else 0 (the rows owned by other ranks are
+ *            added by the all-reduce that follows);
+ *   scatter: dst[idx[i] - row_lo,:] += src[i,:] for the idx[i] in the range (f32 atomics), the others are skipped.  */
+int lkg_gather_rows_range_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                              int64_t row_lo, int64_t row_hi, float *dst, int64_t ldd, void *stream);
+int lkg_scatter_add_rows_range_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                                   int64_t row_lo, int64_t row_hi, float *dst, int64_t ldd, void *stream);
 /* dst[i] = src[perm[i]] for int64 ids                                                              */
 int lkg_gather_i64(int64_t n, const int64_t *src, const int32_t *perm, int64_t *dst, void *stream);
 

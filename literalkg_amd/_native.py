@@ -35,6 +35,8 @@ PROTOTYPES = {
     "lkg_gather_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
     "lkg_scatter_add_rows_f32": [i64, i32, vp, i64, vp, vp, vp, i64, vp],
     "lkg_gather_i64": [i64, vp, vp, vp, vp],
+    "lkg_gather_rows_range_f32": [i64, i32, vp, i64, vp, i64, i64, vp, i64, vp],
+    "lkg_scatter_add_rows_range_f32": [i64, i32, vp, i64, vp, i64, i64, vp, i64, vp],
     "lkg_sample_kg_batch": [i64, i32, u64, vp, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp],
     "lkg_grouped_gemm_f32": [i32, i32, vp, i64, i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, i64, f32, vp, i64,
                              i64, vp],

@@ -96,6 +96,32 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(long n, int d, co
     for (int c = lane; c < d; c += 64) atomicAdd(dst + r * ldd + c, src[i * lds + c]);
 }
 
+// Row-range forms for a table sharded by rows over ranks: this rank holds rows [lo, hi) (src / dst point at row lo).
+//   gather : dst[i,:] = idx[i] in [lo, hi) ? src[idx[i] - lo, :] : 0     (the rows of other ranks arrive by all-reduce)
+//   scatter: dst[idx[i] - lo, :] += src[i,:] for idx[i] in [lo, hi)      (f32 atomics)
+__global__ __launch_bounds__(256) void gather_rows_range_kernel(long n, int d, const float *__restrict__ src, long lds,
+                                                                 const long *__restrict__ idx, long lo, long hi,
+                                                                 float *__restrict__ dst, long ldd) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const long r = idx[i];
+    const bool mine = r >= lo && r < hi;
+    const float *s = src + (mine ? r - lo : 0) * lds;
+    for (int c = lane; c < d; c += 64) dst[i * ldd + c] = mine ? s[c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_range_kernel(long n, int d, const float *__restrict__ src,
+                                                                      long lds, const long *__restrict__ idx, long lo,
+                                                                      long hi, float *__restrict__ dst, long ldd) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const long r = idx[i];
+    if (r < lo || r >= hi) return;
+    for (int c = lane; c < d; c += 64) atomicAdd(dst + (r - lo) * ldd + c, src[i * lds + c]);
+}
+
 __global__ void gather_i64_kernel(long n, const long *__restrict__ src, const int *__restrict__ perm,
                                   long *__restrict__ dst) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -189,6 +215,29 @@ extern "C" int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, 
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (long)n, d, src, (long)lds, (const long *)idx, perm, dst, (long)ldd);
     LKG_CHECK_LAUNCH("lkg_scatter_add_rows_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_gather_rows_range_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                                         int64_t row_lo, int64_t row_hi, float *dst, int64_t ldd, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && lds >= d && ldd >= d && row_lo <= row_hi, "lkg_gather_rows_range_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(idx && dst && (src || row_lo == row_hi), "lkg_gather_rows_range_f32: null pointer");
+    hipLaunchKernelGGL(gather_rows_range_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n, d, src, (long)lds, (const long *)idx, (long)row_lo, (long)row_hi, dst, (long)ldd);
+    LKG_CHECK_LAUNCH("lkg_gather_rows_range_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_scatter_add_rows_range_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
+                                              int64_t row_lo, int64_t row_hi, float *dst, int64_t ldd, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && lds >= d && ldd >= d && row_lo <= row_hi,
+                "lkg_scatter_add_rows_range_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(idx && src && (dst || row_lo == row_hi), "lkg_scatter_add_rows_range_f32: null pointer");
+    hipLaunchKernelGGL(scatter_add_rows_range_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n, d, src, (long)lds, (const long *)idx, (long)row_lo, (long)row_hi, dst, (long)ldd);
+    LKG_CHECK_LAUNCH("lkg_scatter_add_rows_range_f32");
     return LKG_OK;
 }
 

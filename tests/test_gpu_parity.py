@@ -420,10 +420,15 @@ def test_transr_group_reuse_matches_oracle_and_general_path(ops, O, gpu_device, 
          "gat_trans_M": torch.randn(n_rel, c, dout, generator=gen) * 0.2}
     bh, br, bp, bn = (torch.from_numpy(x) for x in make_batch(n, groups, k, seed=k))
     cfg = SimpleNamespace(kg_l2loss_lambda=1e-3)
-    gc = gat.clone().requires_grad_(True)
-    pc = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
-    want = O.triple_loss_transr(pc, cfg, gc, bh, br, bp, bn)
-    want.backward()
+
+    def oracle(dtype):
+        gc = gat.clone().to(dtype).requires_grad_(True)
+        pc = {kk: v.clone().to(dtype).requires_grad_(True) for kk, v in p.items()}
+        want = O.triple_loss_transr(pc, cfg, gc, bh, br, bp, bn)
+        want.backward()
+        return want.detach(), gc.grad, pc["relation_embed.weight"].grad, pc["gat_trans_M"].grad
+    w64 = oracle(torch.float64)                      # what both f32 evaluations approximate
+    w32 = oracle(torch.float32)
     pos_w, neg_w, _ = O.triple_scores_transr(p, gat, bh, br, bp, bn)
     dev = [x.to(gpu_device) for x in (bh, br, bp, bn)]
     assert ops.is_grouped_batch(dev[0], dev[1], dev[2], k)
@@ -431,23 +436,25 @@ def test_transr_group_reuse_matches_oracle_and_general_path(ops, O, gpu_device, 
     broken = dev[2].clone()
     broken[k - 1] = (broken[k - 1] + 1) % n
     assert not ops.is_grouped_batch(dev[0], dev[1], broken, k)
-    grads = {}
+
+    def rel_err(got, ref):
+        return float((got.double().cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
     for group in (k, 1):
         gg = gat.clone().to(gpu_device).requires_grad_(True)
         pg = {kk: v.clone().to(gpu_device).requires_grad_(True) for kk, v in p.items()}
         keep = {}
-        got = ops.transr_loss(gg, pg["relation_embed.weight"], pg["gat_trans_M"], *dev[:1], dev[1], dev[2], dev[3],
+        got = ops.transr_loss(gg, pg["relation_embed.weight"], pg["gat_trans_M"], dev[0], dev[1], dev[2], dev[3],
                               1e-3, keep, group)
         got.backward()
-        assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+        assert abs(float(got) - float(w64[0])) <= 1e-5 * max(1.0, abs(float(w64[0])))
         torch.testing.assert_close(keep["pos"].cpu(), pos_w, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(keep["neg"].cpu(), neg_w, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(gg.grad.cpu(), gc.grad, rtol=1e-3, atol=1e-6)
-        torch.testing.assert_close(pg["relation_embed.weight"].grad.cpu(), pc["relation_embed.weight"].grad, rtol=1e-3,
-                                   atol=1e-6)
-        torch.testing.assert_close(pg["gat_trans_M"].grad.cpu(), pc["gat_trans_M"].grad, rtol=1e-3, atol=1e-6)
-        grads[group] = gg.grad
-    torch.testing.assert_close(grads[k], grads[1], rtol=1e-4, atol=1e-6)
+        # every gradient as close to the f64 result as an f32 evaluation gets (the CPU f32 oracle's own distance is
+        # the yardstick: sums of K products with cancellation, e.g. |S| << sum |terms| in the grouped head gradient)
+        for got_g, i, name in ((gg.grad, 1, "emb"), (pg["relation_embed.weight"].grad, 2, "rel"),
+                               (pg["gat_trans_M"].grad, 3, "W")):
+            e_hip, e_cpu = rel_err(got_g, w64[i]), rel_err(w32[i], w64[i])
+            assert e_hip <= max(8.0 * e_cpu, 2e-6), (group, name, e_hip, e_cpu)
 
 
 def test_out_of_range_relation_raises_one_call_later(ops, gpu_device):
