@@ -129,6 +129,19 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
                      const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                      int32_t long_thresh, void *stream);
 
+/* The same with two optional row-wise extras in the epilogue (both nullable), so that an aggregation layer's
+ * neighbours in the autograd graph cost no pass of their own:
+ *   add2               out[i,:] += add2[i,:]  -- in the backward, the gradient that reaches `ego` through its OTHER use
+ *                      (the concatenated table keeps a copy of the layer input, model.py:300-309), which autograd
+ *                      would otherwise add in a separate N x D pass;
+ *   copy_src/copy_dst  copy_dst[i,:] = copy_src[i,:] -- in the forward, that copy itself (the raw entity table into
+ *                      column slot 0 of the concatenated table when no gate is configured).                      */
+int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                           const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
+                           const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
+                           const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
+                           const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
+
 /* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
  * layer only needs the rows its consumers read.  lkg_csr_extract_rows copies the entries of the (sorted,
  * int64) rows sel_rows into a compact CSR whose offsets out_rowptr int32[n_sel+1] the caller has already

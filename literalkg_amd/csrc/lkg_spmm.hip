@@ -107,6 +107,23 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
     }
 }
 
+// Optional row-wise extras of the epilogue (lkg_spmm_csr_fused_f32): a second addend and a row copy riding along.
+struct SpmmExtra {
+    const float *add2;       // out[i,:] += add2[i,:]
+    long ld_add2;
+    const float *copy_src;   // copy_dst[i,:] = copy_src[i,:]
+    long ld_copy_src;
+    float *copy_dst;
+    long ld_copy_dst;
+    __device__ __forceinline__ void shift(long cols) {
+        if (add2) add2 += cols;
+        if (copy_dst) {
+            copy_src += cols;
+            copy_dst += cols;
+        }
+    }
+};
+
 // V: float4 (16-byte chunks) or float.  LPE: lanes per edge.  CPL: chunks per lane.  U: edges in flight.
 // FULL: nchunk == LPE * CPL, i.e. no lane ever falls outside the row (drops the per-load guard).
 //
@@ -125,7 +142,8 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                                                         float *__restrict__ out, long ldo,
                                                         const float *__restrict__ self, long ld_self,
                                                         const int *__restrict__ long_rows, int n_long,
-                                                        int long_thresh, int blocks_per_slab, int slab_cols) {
+                                                        int long_thresh, int blocks_per_slab, int slab_cols,
+                                                        SpmmExtra ex) {
     using ops = vec_ops<V>;
     __shared__ V part[4][CPL][LPE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -136,6 +154,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     x += (long)slab * slab_cols;
     out += (long)slab * slab_cols;
     if (self) self += (long)slab * slab_cols;
+    ex.shift((long)slab * slab_cols);
     const bool team = bid < n_long;     // workgroup-uniform
     int row;
     if (team) {
@@ -171,12 +190,17 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
         const V *own = self ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
+        const V *own2 = ex.add2 ? reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2) : nullptr;
+        const V *csrc = ex.copy_dst ? reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src) : nullptr;
+        V *cdst = ex.copy_dst ? reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst) : nullptr;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int chunk = lane + i * LPE;
             if (FULL || chunk < nchunk) {
                 if (own) ops::fma(acc[i], 1.f, own[chunk]);   // out = self + A @ x  (ego + side, model.py:109)
+                if (own2) ops::fma(acc[i], 1.f, own2[chunk]);
                 dst[chunk] = acc[i];
+                if (cdst) cdst[chunk] = csrc[chunk];
             }
         }
     }
@@ -205,7 +229,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
                                                                 float *__restrict__ out, long ldo,
                                                                 const float *__restrict__ self, long ld_self,
                                                                 const int *__restrict__ long_rows, int n_long,
-                                                                int long_thresh) {
+                                                                int long_thresh, SpmmExtra ex) {
     using ops = vec_ops<V>;
     static_assert(LPE <= 32 && LPE % U == 0, "grouped SpMM: 2+ rows per wave, whole U-groups per chunk");
     __shared__ V part[4][LPE];
@@ -224,7 +248,11 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
 #pragma unroll
         for (int k = 1; k < 4; ++k) ops::fma(a, 1.f, part[k][lane]);
         if (self) ops::fma(a, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[lane]);
+        if (ex.add2) ops::fma(a, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[lane]);
         reinterpret_cast<V *>(out + (long)row * ldo)[lane] = a;
+        if (ex.copy_dst)
+            reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst)[lane] =
+                reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src)[lane];
         return;
     }
     constexpr int RPW = 64 / LPE;
@@ -276,20 +304,24 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
     if (mine && (FULL || sl < nchunk)) {
         if (len == 0) acc = ops::zero();   // an empty row is exactly 0 (0 * Inf/NaN of the spare gathers must not leak)
         if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[sl]);
+        if (ex.add2) ops::fma(acc, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[sl]);
         reinterpret_cast<V *>(out + (long)row * ldo)[sl] = acc;
+        if (ex.copy_dst)
+            reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst)[sl] =
+                reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src)[sl];
     }
 }
 
 template <typename V, int LPE, int U, bool FULL>
 int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
                    int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows,
-                   int n_long, int long_thresh, hipStream_t s) {
+                   int n_long, int long_thresh, const SpmmExtra &ex, hipStream_t s) {
     constexpr int rows_per_block = 4 * (64 / LPE);
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block + n_long;
     LKG_REQUIRE(blocks * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)", (long long)blocks);
     hipLaunchKernelGGL((spmm_csr_grouped_kernel<V, LPE, U, FULL>), dim3((unsigned)blocks), dim3(256), 0, s,
                        (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
-                       long_rows, n_long, long_thresh);
+                       long_rows, n_long, long_thresh, ex);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
@@ -297,13 +329,13 @@ int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col
 template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
            int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
-           int long_thresh, int n_slabs, int slab_cols, hipStream_t s) {
+           int long_thresh, int n_slabs, int slab_cols, const SpmmExtra &ex, hipStream_t s) {
     const int64_t blocks = (n_rows + 3) / 4 + n_long;
     LKG_REQUIRE(blocks * n_slabs * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)",
                 (long long)(blocks * n_slabs));
     hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0, s,
                        (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
-                       long_rows, n_long, long_thresh, (int)blocks, slab_cols);
+                       long_rows, n_long, long_thresh, (int)blocks, slab_cols, ex);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
     return LKG_OK;
 }
@@ -311,18 +343,18 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
              int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
-             int long_thresh, int n_slabs, int slab_cols, hipStream_t s) {
+             int long_thresh, int n_slabs, int slab_cols, const SpmmExtra &ex, hipStream_t s) {
 #define LKG_GO(LPE, CPL, U)                                                                              \
     return (nchunk == LPE * CPL)                                                                         \
                ? launch<V, LPE, CPL, U, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
-                                              long_rows, n_long, long_thresh, n_slabs, slab_cols, s)      \
+                                              long_rows, n_long, long_thresh, n_slabs, slab_cols, ex, s)  \
                : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
-                                               long_rows, n_long, long_thresh, n_slabs, slab_cols, s)
+                                               long_rows, n_long, long_thresh, n_slabs, slab_cols, ex, s)
     if (nchunk <= 8)   // rows of <= 32 floats: 8 rows per wave (see spmm_csr_grouped_kernel)
         return (nchunk == 8) ? launch_grouped<V, 8, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
-                                                            ld_self, long_rows, n_long, long_thresh, s)
+                                                            ld_self, long_rows, n_long, long_thresh, ex, s)
                              : launch_grouped<V, 8, 8, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
-                                                             ld_self, long_rows, n_long, long_thresh, s);
+                                                             ld_self, long_rows, n_long, long_thresh, ex, s);
     if (nchunk <= 16) LKG_GO(16, 1, 4);
     if (nchunk <= 32) LKG_GO(32, 1, 4);
     if (nchunk <= 64) LKG_GO(64, 1, 4);
@@ -334,10 +366,11 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
 
 }  // namespace
 
-extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
-                                const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
-                                const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
-                                int32_t long_thresh, void *stream) {
+extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                                      const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
+                                      const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
+                                      const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
+                                      const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -348,8 +381,16 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     LKG_REQUIRE(rowptr && x && out, "lkg_spmm_csr_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
     LKG_REQUIRE(!self || ld_self >= d, "lkg_spmm_csr_f32: self stride %lld smaller than d=%d", (long long)ld_self, d);
+    LKG_REQUIRE(!add2 || ld_add2 >= d, "lkg_spmm_csr_fused_f32: add2 stride %lld smaller than d=%d", (long long)ld_add2, d);
+    LKG_REQUIRE(!copy_dst || (copy_src && ld_copy_src >= d && ld_copy_dst >= d),
+                "lkg_spmm_csr_fused_f32: the row copy needs a source and strides >= d=%d", d);
     const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out) &&
-                     (!self || (ld_self % 4 == 0 && lkg_aligned16(self)));
+                     (!self || (ld_self % 4 == 0 && lkg_aligned16(self))) &&
+                     (!add2 || (ld_add2 % 4 == 0 && lkg_aligned16(add2))) &&
+                     (!copy_dst || (ld_copy_src % 4 == 0 && ld_copy_dst % 4 == 0 && lkg_aligned16(copy_src) &&
+                                    lkg_aligned16(copy_dst)));
+    const SpmmExtra ex{add2, (long)ld_add2, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
+                       (long)ld_copy_dst};
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
     // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
@@ -359,18 +400,28 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
     const int block_cols = vec ? 128 : 256;
     if (d > block_cols && d % block_cols == 0)     // equal slabs: one launch, slab-major workgroup order
         return vec ? dispatch<float4>(n_rows, block_cols / 4, rowptr, col, val, x, ldx, out, ldo, self, ld_self,
-                                      long_rows, n_long, long_thresh, d / block_cols, block_cols, s)
+                                      long_rows, n_long, long_thresh, d / block_cols, block_cols, ex, s)
                    : dispatch<float>(n_rows, block_cols, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
-                                     n_long, long_thresh, d / block_cols, block_cols, s);
+                                     n_long, long_thresh, d / block_cols, block_cols, ex, s);
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
+        const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, copy_dst ? copy_src + c0 : nullptr,
+                            (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
-                                        self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, s)
+                                        self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
-                                       self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, s);
+                                       self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s);
         if (rc != LKG_OK) return rc;
     }
     return LKG_OK;
+}
+
+extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
+                                const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
+                                const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
+                                int32_t long_thresh, void *stream) {
+    return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr, 0,
+                                  nullptr, 0, long_rows, n_long, long_thresh, stream);
 }
 
 // dst[i] = src[perm[i]]

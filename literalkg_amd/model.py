@@ -39,6 +39,21 @@ class AttentionCSR:
         return ops.aggregate(ego, self.graph, self.val, self.val_t, plus_self)
 
 
+class _KeepingAttention:
+    """A_in for the FIRST layer: its aggregation also produces the copy of the layer input that gat_embeddings keeps
+    as slot 0 of the concatenated table (ops._AggregateKeep), forward copy and backward sum fused into the SpMM."""
+
+    def __init__(self, att: AttentionCSR, keep_dst: torch.Tensor):
+        self.att, self.keep_dst, self.kept = att, keep_dst, None
+
+    def aggregate(self, ego: torch.Tensor, plus_self: bool = False) -> torch.Tensor:
+        a = self.att
+        if self.kept is not None:                 # a layer that aggregates twice keeps once
+            return a.aggregate(ego, plus_self)
+        side, self.kept = ops.aggregate_keep(ego, a.graph, a.val, a.val_t, plus_self, self.keep_dst)
+        return side
+
+
 def _xavier(linear: nn.Linear) -> nn.Linear:
     nn.init.xavier_uniform_(linear.weight)
     return linear
@@ -137,7 +152,7 @@ class Aggregator(nn.Module):
                 z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
             return self._finish(z)
         if kind == "bi-interaction":
-            s = self._lin(self.linear1, self.residual_connection(ego + side, h0, lamda, alpha, l))
+            s = self._lin(self.linear1, self.residual_connection(ops.axpby(ego, side), h0, lamda, alpha, l))
             b = self._lin(self.linear2, self.residual_connection(ops.mul(ego, side), h0, lamda, alpha, l))
             # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): one kernel, then a slope-1
             # epilogue for the LayerNorm
@@ -283,10 +298,15 @@ class LiteralKG(nn.Module):
         kept = [cur]
         for idx, layer in enumerate(self.aggregator_layers):
             layer.norm_out = cb.slot(idx + 1)
+            # layer 1 on the device structure: its SpMM also leaves the layer input in slot 0 (no copy pass) and its
+            # backward sums the two gradients of that input in the same launch
+            a_k = _KeepingAttention(att, cb.slot(0)) if (idx == 0 and isinstance(att, AttentionCSR)) else att
             try:
-                cur = layer(cur, att, kept, self.lamda, self.alpha, idx + 1)
+                cur = layer(cur, a_k, kept, self.lamda, self.alpha, idx + 1)
             finally:
                 layer.norm_out = None
+            if a_k is not att and a_k.kept is not None:
+                kept[0] = a_k.kept
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused
         cat = ops.assemble_cat(cb, kept)
         if self.scale_gat_dim is not None:

@@ -96,10 +96,12 @@ def check_deferred_errors():
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
-             add_self: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[i,:] = (add_self[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows described
-    by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
-    a row-range shard hand over only ITS rows of x while col keeps global ids."""
+             add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
+             copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
+    described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
+    a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
+    epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own)."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -107,10 +109,16 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
         out = torch.empty((n_rows, d), dtype=torch.float32, device=x.device)
     if add_self is not None:
         add_self = _f32_rows(add_self)
-    N.call("lkg_spmm_csr_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
+    if add2 is not None:
+        add2 = _f32_rows(add2)
+    csrc, cdst = (_f32_rows(copy[0]), copy[1]) if copy is not None else (None, None)
+    if cdst is not None and (cdst.stride(1) != 1 or cdst.shape != (n_rows, d)):
+        raise ValueError("spmm_raw: copy destination must be an n_rows x d view with unit column stride")
+    N.call("lkg_spmm_csr_fused_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
            x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
-           _ld(add_self) if add_self is not None else 0, N.ptr(long_rows),
-           0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
+           _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
+           N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
+           N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
     return out
 
 
@@ -210,6 +218,42 @@ def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch
               plus_self: bool = False) -> torch.Tensor:
     """side = A @ ego, or ego + side in one pass when plus_self."""
     return _Aggregate.apply(ego, g, val, val_t, plus_self)
+
+
+class _AggregateKeep(Function):
+    """The first aggregation layer together with the OTHER consumer of its input: gat_embeddings keeps the layer
+    input itself as column slot 0 of the concatenated table (model.py:300-309).  Returns (side, kept): kept is ego --
+    copied into ``keep_dst`` by the SpMM's epilogue when ego is not stored there already (the raw entity table, no
+    gate).  Backward: A^T g_side (+ g_side) + g_kept in ONE launch (autograd would add the two contributions to ego
+    in a separate N x D pass)."""
+
+    @staticmethod
+    def forward(ctx, ego, g: KGStructure, val, val_t, plus_self, keep_dst):
+        _need_gpu(ego, val)
+        ctx.g, ctx.val_t, ctx.plus_self = g, val_t, plus_self
+        ctx.set_materialize_grads(False)
+        copy = None
+        kept = ego
+        if keep_dst is not None and (keep_dst.data_ptr() != ego.data_ptr() or keep_dst.stride() != ego.stride()):
+            copy, kept = (ego, keep_dst), keep_dst
+        side = spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
+                        add_self=ego if plus_self else None, copy=copy)
+        return side, kept          # kept may be the input itself: autograd aliases it as this node's output
+
+    @staticmethod
+    def backward(ctx, g_side, g_kept):
+        g = ctx.g
+        if g_side is None:
+            return g_kept, None, None, None, None, None
+        if g.t_rowptr is None:
+            raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
+        g_side = _f32_rows(g_side)
+        return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
+                        add_self=g_side if ctx.plus_self else None, add2=g_kept), None, None, None, None, None
+
+
+def aggregate_keep(ego, g: KGStructure, val, val_t, plus_self: bool = False, keep_dst: Optional[torch.Tensor] = None):
+    return _AggregateKeep.apply(ego, g, val, val_t, plus_self, keep_dst)
 
 
 # ----------------------------------------------------------------------------- dense layers on the MFMA GEMM
