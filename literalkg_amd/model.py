@@ -387,11 +387,10 @@ class LiteralKG(nn.Module):
                         for a, b in zip((h_list, t_list, r_list), c[2]))):
             return self._triple_graph
         h, t, r = h_list, t_list, r_list
-        if relations is not None:
+        if relations is not None:      # the reference only visits `relations` (model.py:451): other triples are dropped
             rel_ids = torch.as_tensor(list(relations), dtype=r.dtype, device=r.device)
-            present = torch.unique(r)
-            if not bool(torch.isin(present, rel_ids).all()):   # the reference only visits `relations`
-                keep = torch.isin(r, rel_ids)
+            keep = torch.isin(r, rel_ids)
+            if not bool(keep.all()):
                 h, t, r = h[keep], t[keep], r[keep]
         g = KGStructure.from_triples(self.n_entities, h, t, r, device=dev)
         self._triple_graph = g
