@@ -27,7 +27,8 @@ def main():
             name = r["Kernel_Name"]
             if flt and flt not in name:
                 continue
-            short = name.split("(")[0].replace("void (anonymous namespace)::", "").strip() or name[:60]
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "")
+            short = short.split("(")[0].strip() or name[:60]
             groups[(short, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))].append(
                 int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     rows = []
