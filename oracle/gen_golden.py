@@ -245,6 +245,32 @@ def loader_laplacian_case(name, n, h, t, r):
     save(name, **out)
 
 
+def loader_sampler_case(name, n, h, t, r, neg_rate, seed):
+    """DataLoader.generate_kg_batch (dataloader.py:283-316 with its helpers 249-281, 318-330) run by the reference's own
+    code under fixed seeds of the two generators it draws from (``random`` and ``numpy.random``).  Only the branch with
+    fewer groups than heads (random.sample) can run: the other one calls random.choice on a dict_keys view, which raises
+    TypeError under Python 3 (dataloader.py:290-291)."""
+    import collections
+    import random
+    sys.path.insert(0, REF)
+    import dataloader as ref_dl
+    dl = object.__new__(ref_dl.DataLoader)
+    dl.pre_training_neg_rate = neg_rate
+    kg = collections.defaultdict(list)
+    for hh, tt, rr in zip(h.tolist(), t.tolist(), r.tolist()):
+        kg[hh].append((tt, rr))                                  # construct_data, dataloader.py:402
+    tails = t.tolist()                                           # list(data.training_tails), main_pretraining.py:101
+    out = dict(n=np.int64(n), h=h, t=t, r=r, neg_rate=np.int64(neg_rate), seed=np.int64(seed))
+    half = {k: kg[k] for k in list(kg.keys())[::2]}              # an epoch's sampled dict (main_pretraining.py:93-96)
+    for tag, d, bs in (("a", kg, 60 * neg_rate), ("b", half, 25 * neg_rate)):
+        random.seed(seed)
+        np.random.seed(seed)
+        bh, br, bp, bn = dl.generate_kg_batch(d, bs, tails)
+        out.update({f"{tag}_batch_size": np.int64(bs), f"{tag}_heads": np.array(list(d.keys()), np.int64),
+                    f"{tag}_h": bh.numpy(), f"{tag}_r": br.numpy(), f"{tag}_p": bp.numpy(), f"{tag}_n": bn.numpy()})
+    save(name, **out)
+
+
 def mlp_case(cls, name, args, n, h, t, r, seed, rng, init_mlp):
     """mode='mlp' (model.py:499-519 / model_bce.py:423-436): train-mode forward (BatchNorm batch statistics, running
     buffers updated), BCE backward as main_finetuning_BCE.py does, then an eval-mode forward."""
@@ -292,6 +318,11 @@ def main():
         mlp_case(ref_model.LiteralKG, "mlp_model_gcn_l1_scale", make_args(scale_gat_dim=24), 220, mh, mt, mr, 61, rng, True)
         mlp_case(ref_model_bce.LiteralKG, "mlp_bce_gcn_l2_scale", make_args(scale_gat_dim=16, n_conv_layers=2), 220, mh,
                  mt, mr, 62, rng, False)
+        return
+    if "--only-sampler" in sys.argv:
+        rng = np.random.default_rng(909)
+        sh, st, sr = random_graph(rng, 300, 2400, 5, 10)
+        loader_sampler_case("sampler_ref_batch", 300, sh, st, sr, 4, 31)
         return
     if "--only-laplacian" in sys.argv:
         rng = np.random.default_rng(4242)

@@ -706,6 +706,64 @@ def test_kg_batch_sampler_contract(L, gpu_device):
             s.sample(k * 2, heads=torch.tensor(bad, device=gpu_device), seed=3)
 
 
+def test_kg_batch_sampler_distribution_matches_the_oracle(L, gpu_device):
+    """f2: the device sampler against oracle/sampler_oracle.py (the restatement of dataloader.py:249-330 that is pinned
+    bit for bit on a batch of the reference): ~1e6 draws from each, chi-square two-sample tests per head class on
+    (a) which positive triple a head gets (uniform over its triples), (b) which tails come out as negatives (tail
+    multiplicity in the triple list, minus the head's (tail, relation) positives, distinct inside a group)."""
+    import random
+    from literalkg_amd.sampler import KGBatchSampler
+    from oracle import sampler_oracle as S
+    rng = np.random.default_rng(12)
+    n, n_rel, k = 400, 4, 5
+    h, t, r = rand_graph(rng, n, 6000, n_rel=n_rel, long_rows=[(7, 250)])
+    t = np.minimum((n * rng.random(len(t)) ** 2).astype(np.int64), n - 1)            # skewed tail multiplicity
+    extra = np.stack([h[:80], (r[:80] + 1) % n_rel, t[:80]], 1)                       # (h,t) under two relations
+    trip = np.unique(np.concatenate([np.stack([h, r, t], 1), extra]), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    kg = S.build_kg_dict(h, t, r)
+    deg = np.bincount(h, minlength=n)
+    classes = {"low (1-4 triples)": np.flatnonzero((deg >= 1) & (deg <= 4))[:12],
+               "mid (10-30 triples)": np.flatnonzero((deg >= 10) & (deg <= 30))[:12],
+               "long row": np.array([7])}
+    sampler = KGBatchSampler(g, k)
+    triple_id = {tr: i for i, tr in enumerate(map(tuple, trip.tolist()))}
+
+    def chi2_two_sample(a, b):
+        keep = (a + b) > 0
+        a, b = a[keep].astype(float), b[keep].astype(float)
+        ka, kb = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())
+        return float((((ka * a - kb * b) ** 2) / (a + b)).sum()), int(keep.sum()) - 1
+
+    for name, heads in classes.items():
+        groups = 70_000 if len(heads) > 1 else 40_000
+        random.seed(5)
+        np.random.seed(5)
+        pool = {int(x): kg[int(x)] for x in heads}
+        # the oracle draws heads with random.choice when there are more groups than heads: same head law as the device
+        oh, orr, op, on = S.generate_kg_batch(pool, groups * k, k, t.tolist())
+        dh, dr, dp, dn = (x.cpu().numpy() for x in
+                          sampler.sample(groups * k, heads=torch.from_numpy(heads).to(gpu_device), seed=77))
+        assert dh.shape == oh.shape
+        # (a) positive triples: counts per (h, r, t+) over the class
+        cnt = lambda hh, rr, pp: np.bincount([triple_id[x] for x in zip(hh[::k].tolist(), rr[::k].tolist(),
+                                                                    pp[::k].tolist())], minlength=len(trip))
+        stat, df = chi2_two_sample(cnt(dh, dr, dp), cnt(oh, orr, op))
+        assert stat < df + 5 * np.sqrt(2 * df) + 10, (name, "positives", stat, df)
+        # uniform over the head's triples, head by head (device alone, exact expectation)
+        dc = cnt(dh, dr, dp)
+        for hh in heads[:4]:
+            ids = [triple_id[(int(hh), rr, tt)] for tt, rr in kg[int(hh)]]
+            obs = dc[ids].astype(float)
+            exp = obs.sum() / len(ids)
+            s = float(((obs - exp) ** 2 / exp).sum())
+            assert s < (len(ids) - 1) + 5 * np.sqrt(2 * max(len(ids) - 1, 1)) + 10, (name, "uniform positives", s)
+        # (b) negative tails
+        stat, df = chi2_two_sample(np.bincount(dn, minlength=n), np.bincount(on, minlength=n))
+        assert stat < df + 5 * np.sqrt(2 * df) + 10, (name, "negatives", stat, df)
+
+
 def test_attention_row_range_refresh_leaves_other_rows_alone(L, ops, gpu_device):
     """A row-range refresh into an existing value array (out=) on a graph WITH duplicate (h,t) pairs: the entries of
     the other rows keep their values (only this call's entry range is cleared for the duplicate pre-pass)."""

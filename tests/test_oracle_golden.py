@@ -171,3 +171,27 @@ def test_mlp_head(name):
     with torch.no_grad():
         out_eval = O.mlp_head(p, O.gat_embeddings(p, cfg, _a_in(g)), heads, tails, training=False).reshape(-1)
     np.testing.assert_allclose(out_eval.numpy(), g["out_eval"], rtol=TOL, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- f2 batch sampler restatement
+def test_sampler_oracle_reproduces_the_reference_batches():
+    """oracle/sampler_oracle.py draws from the same generators in the same order as dataloader.py:249-330: under the
+    fixture's seeds it returns the reference's batch element for element."""
+    import random
+    from oracle import sampler_oracle as S
+    g = load_golden("sampler_ref_batch")
+    kg = S.build_kg_dict(g["h"], g["t"], g["r"])
+    tails = g["t"].tolist()
+    k, seed = int(g["neg_rate"]), int(g["seed"])
+    for tag in ("a", "b"):
+        d = {int(h): kg[int(h)] for h in g[f"{tag}_heads"]}
+        random.seed(seed)
+        np.random.seed(seed)
+        bh, br, bp, bn = S.generate_kg_batch(d, int(g[f"{tag}_batch_size"]), k, tails)
+        assert np.array_equal(bh, g[f"{tag}_h"]) and np.array_equal(br, g[f"{tag}_r"])
+        assert np.array_equal(bp, g[f"{tag}_p"]) and np.array_equal(bn, g[f"{tag}_n"])
+        # the contract the device sampler is held to as well
+        pos = set(zip(g["h"].tolist(), g["r"].tolist(), g["t"].tolist()))
+        for hh, rr, pp, negs in zip(bh[::k], br[::k], bp[::k], bn.reshape(-1, k)):
+            assert (hh, rr, pp) in pos and len(set(negs.tolist())) == k
+            assert all((hh, rr, x) not in pos for x in negs)
