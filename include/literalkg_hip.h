@@ -338,10 +338,11 @@ int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
 int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                            int64_t ldg, const float *zpre, int64_t ldz, float *out, int64_t ldo,
                            void *stream);
+/* activated != 0: gpre / zpre hold tanh(g) / sigmoid(z) (what the fused gate epilogue of lkg_gemm_tall_f32 keeps).   */
 int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                            int64_t ldg, const float *zpre, int64_t ldz, const float *g_out,
                            int64_t ldgo, float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg,
-                           float *g_zpre, int64_t ldgz, void *stream);
+                           float *g_zpre, int64_t ldgz, int32_t activated, void *stream);
 
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
@@ -375,6 +376,36 @@ int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg
 int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                  int64_t ldc, const float *bias, void *stream);
+
+/* Tall GEMM of the layers' dense part (lkg_gemm_tall.hip): m rows (entities), n <= a few hundred output columns,
+ *   C[m, n] = epilogue( sum over K-panels p of  A_p[m, ka[p]] . B_p[n, ka[p]]^T )            f32 in, f32 out.
+ * Arithmetic "f16 x 2": rows of A and of B are scaled by powers of two, every element split exactly into two fp16
+ * (11 + 11 significant bits), three v_mfma_f32_32x32x16_f16 per 16 k into a main and a correction accumulator (f32),
+ * unscaled exactly in the epilogue: within ~2x of an f32 GEMM's rounding error against f64, at 3/8 of the f32 MFMA's
+ * instruction count on a 16x faster pipe.
+ *   a / lda / ka       host arrays of n_panels (1..3) device pointers / row strides / widths: A's K-panels, possibly
+ *                      from different arrays (nn.Linear over a concatenated input WITHOUT the concatenation:
+ *                      gate.py:23 [x | num | txt], model.py:116 [ego | side]); any alignment, any width;
+ *   a_rowmax           device float[m]: max_k |A[i, k]| over all panels (lkg_row_absmax_f32; accumulate = 1 folds a
+ *                      further panel in).  It only has to BOUND the row (a stale larger value costs precision, a
+ *                      smaller one overflows fp16): callers cache it for constant panels;
+ *   b / ldb            host arrays of n_groups * n_panels device pointers: block (group, panel) of B.  trans_b = 1:
+ *                      stored [rows][ka[p]] (an nn.Linear weight or a column slice of one), 0: stored [ka[p]][rows]
+ *                      (the data gradient  gy . W).  n_groups = 1: rows = n.  Epilogue 1 (gate): n_groups = 2 row
+ *                      groups of n / 2 (the g and the z projection of gate.py:22-25), bias = [b_g | b_z], and
+ *                      C[m, n/2] = (1 - sigmoid(z)) gate_x + sigmoid(z) tanh(g)   (gate.py:26) with tanh(g) / sigmoid(z)
+ *                      optionally kept in gate_g / gate_z for lkg_gate_blend_bwd_f32(activated = 1);
+ *   epilogue 0         C = alpha * product + beta * C + bias[n];
+ *   workspace          >= lkg_gemm_tall_workspace(n, n_panels, ka, epilogue) bytes (B's fp16 planes: no allocation here). */
+int lkg_row_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, int32_t accumulate,
+                       void *stream);
+int64_t lkg_gemm_tall_workspace(int32_t n, int32_t n_panels, const int32_t *ka, int32_t epilogue);
+int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
+                      const int32_t *ka, const float *a_rowmax, int32_t n_groups, const float *const *b,
+                      const int64_t *ldb, int32_t trans_b, float alpha, float beta, float *c, int64_t ldc,
+                      const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
+                      int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
+                      void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,526 @@
+// Tall f32 GEMM for the dense part of the layers (nn.Linear forward / data gradient, the literal gate): M = entities
+// (millions), N <= a few hundred, K <= ~1000, f32 in / f32 out.
+//
+//   C[m, n] = epilogue( sum over K-panels p of  A_p[m, K_p] . B_p[n, K_p]^T )
+//
+// Arithmetic: "f16 x 2" on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 2.5 PF dense) with f32 accumulation.
+//   Every row of A (and every row of B = output column) is scaled by a power of two so that its largest magnitude lies
+//   in [2^13, 2^14), then every element is split into  hi = fp16(a') (round toward zero: the residual is then exact)  and
+//   mid = fp16((a' - hi) * 2^11)  -- 11 + 11 significant bits, both in fp16's NORMAL range for every element down to
+//   2^-27 of its row's maximum (below that the absolute error is < 2^-39 of the row maximum).  Then
+//       a'.b' = hi_a hi_b + 2^-11 (hi_a mid_b + mid_a hi_b) + O(2^-22 |a'||b'|)
+//   three MFMAs per 16 k and 32x32 tile -- into TWO accumulators (main, correction), combined and unscaled (an exact
+//   ldexp by -(e_row + e_col)) in the epilogue -- instead of the six of the bf16 x 3 engine or the eight 32x32x2 f32
+//   MFMAs.  Against f64 the result is within ~2x of an f32 GEMM's own rounding error (products carry 2^-22 instead of
+//   2^-24; the f32 accumulation over K dominates either way).
+//
+// K-panels: A may be given as up to three column panels from DIFFERENT arrays (the gate's [x | num | txt], gate.py:23,
+// graphsage's [ego | side]); the accumulators stay in registers across panels, so no concatenation and no C
+// read-modify-write.  B rows may come from two stacked weight groups (the gate's g and z projections) interleaved in
+// blocks of 32 so that one lane holds g[row, c] and z[row, c]: the blend (gate.py:24-26) happens in the epilogue.
+//
+// Tile: 128 rows x BN columns (BN = 256: a layer's whole width, A is read and split ONCE; 128 for narrow outputs),
+// 16-k steps, 2 x BN/64 waves of 64 x 64, double-buffered LDS planes, one barrier per step: barrier -> split + write
+// tile t+1 -> re-issue the loads of tile t+2 -> 12 MFMAs of tile t.  B arrives as ready-made fp16 planes (prepared once
+// per call in the caller's workspace, an exact image of the LDS tile).
+#include <algorithm>
+
+#include "lkg_common.h"
+
+namespace {
+
+constexpr int TM = 128, TK = 16, MAX_PANELS = 3;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_PLAIN = 0, EPI_GATE = 1 };
+
+struct TallArgs {
+    long m;
+    int n;                       // GEMM width (stacked width 2 d for the gate)
+    int n_panels;
+    const float *a[MAX_PANELS];
+    long lda[MAX_PANELS];
+    int ka[MAX_PANELS];
+    int ktiles[MAX_PANELS];
+    int ktiles_total;
+    const float *a_rowmax;       // float[m]: max |A[i, :]| over all panels
+    const _Float16 *bp;          // planes [tiles_n][ktiles_total][2][BN][16]
+    const int *eb;               // int32[tiles_n * BN] exponents of the (stacked, interleaved) B rows
+    float alpha, beta;
+    float *c;
+    long ldc;
+    const float *bias;           // float[n] in GEMM column order (stacked for the gate), nullable
+    // gate epilogue: out = (1 - sigmoid(z)) x + sigmoid(z) tanh(g)
+    const float *x;
+    long ldx;
+    float *g_out, *z_out;        // nullable: tanh(g) / sigmoid(z) kept for the backward
+    long ldg, ldz;
+    int tiles_m, tiles_n;
+};
+
+// exponent e with max * 2^e in [2^13, 2^14)   (0 for max == 0 / denormal; clamped so that ldexp stays finite)
+__device__ __forceinline__ int scale_exponent(float mx) {
+    const int ex = (__float_as_int(mx) >> 23) & 0xff;
+    if (ex == 0 || ex == 0xff) return 0;
+    return max(-100, min(100, 13 - (ex - 127)));
+}
+
+// one element group -> hi / mid fp16 pairs
+__device__ __forceinline__ void split2(float a0, float a1, fp16x2 &hi, fp16x2 &mid) {
+    hi = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+    const float r0 = (a0 - (float)hi[0]) * 2048.f, r1 = (a1 - (float)hi[1]) * 2048.f;
+    mid = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+}
+
+// element (row, k) of a plane: rows of 16 halves, the two 8-half groups swapped on rows 16-31 of every 32 (conflict-free
+// ds_read_b128 fragments, as in lkg_gemm.hip)
+__device__ __forceinline__ int plane_off(int row, int k) { return row * TK + ((((k >> 3) ^ ((row >> 4) & 1)) << 3) | (k & 7)); }
+
+template <int BN>
+__device__ __forceinline__ f16x8 frag(const _Float16 *plane, int r0, int lane) {
+    return *reinterpret_cast<const f16x8 *>(plane + (r0 + (lane & 31)) * TK + (((lane >> 5) ^ ((lane >> 4) & 1)) << 3));
+}
+
+// ---------------------------------------------------------------------------------------------- B preparation
+struct BDesc {
+    const float *ptr[2][MAX_PANELS];     // [group][panel]
+    long ld[2][MAX_PANELS];
+    int k[MAX_PANELS];
+    int n_groups, n_panels, rows_per_group, trans_b;   // trans_b: 1 = stored [rows][K] (nn.Linear weight), 0 = [K][rows]
+    int interleave;                      // 2 groups: tile column s -> group (s / 32) & 1, row (s / 64) * 32 + s % 32
+};
+
+__device__ __forceinline__ bool b_source(const BDesc &b, int s, int &group, int &row) {
+    if (b.interleave) {
+        group = (s >> 5) & 1;
+        row = (s >> 6) * 32 + (s & 31);
+    } else {
+        group = 0;
+        row = s;
+    }
+    return row < b.rows_per_group && group < b.n_groups;
+}
+
+__device__ __forceinline__ float b_elem(const BDesc &b, int group, int row, int p, int k) {
+    const float *src = b.ptr[group][p];
+    return b.trans_b ? src[(long)row * b.ld[group][p] + k] : src[(long)k * b.ld[group][p] + row];
+}
+
+// exponent of every stacked B row (thread per row; B is a few hundred KB)
+__global__ void b_exponent_kernel(BDesc b, int n_stacked, int *__restrict__ eb) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_stacked) return;
+    int group, row;
+    float mx = 0.f;
+    if (b_source(b, s, group, row))
+        for (int p = 0; p < b.n_panels; ++p)
+            for (int k = 0; k < b.k[p]; ++k) mx = fmaxf(mx, fabsf(b_elem(b, group, row, p, k)));
+    eb[s] = scale_exponent(mx);
+}
+
+// planes of one (n tile, k tile): thread = tile row
+template <int BN>
+__global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total, const int *__restrict__ eb,
+                                                      _Float16 *__restrict__ out) {
+    const int tn = blockIdx.x / ktiles_total, kt = blockIdx.x % ktiles_total;
+    int p = 0, k0 = kt;
+    while (p < b.n_panels - 1 && k0 >= (b.k[p] + TK - 1) / TK) {
+        k0 -= (b.k[p] + TK - 1) / TK;
+        ++p;
+    }
+    k0 *= TK;
+    const int s = tn * BN + threadIdx.x;
+    int group, row;
+    const bool ok = b_source(b, s, group, row);
+    const int e = eb[s];
+    _Float16 *dst = out + (long)blockIdx.x * (2 * BN * TK);
+#pragma unroll
+    for (int k = 0; k < TK; k += 2) {
+        float v0 = 0.f, v1 = 0.f;
+        if (ok && k0 + k < b.k[p]) v0 = ldexpf(b_elem(b, group, row, p, k0 + k), e);
+        if (ok && k0 + k + 1 < b.k[p]) v1 = ldexpf(b_elem(b, group, row, p, k0 + k + 1), e);
+        fp16x2 hi, mid;
+        split2(v0, v1, hi, mid);
+        const int off = plane_off(threadIdx.x, k);
+        *reinterpret_cast<fp16x2 *>(dst + off) = hi;
+        *reinterpret_cast<fp16x2 *>(dst + BN * TK + off) = mid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the GEMM
+template <int BN, int EPI>
+__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_kernel(TallArgs g) {
+    constexpr int NT = 2 * BN;                    // threads
+    constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
+    constexpr int TPR = TK / EPT;                 // threads per A row
+    constexpr int APL = TM * TK, BPL = BN * TK;   // halves per plane
+    constexpr int BUF = 2 * APL + 2 * BPL;        // halves per buffer
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BUF + 2 * TM];   // (one object: planes, then the row exponents)
+    int *ea_s = reinterpret_cast<int *>(smem + 2 * BUF);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / (BN / 64), wn = wave % (BN / 64);
+    // XCD-aware order: every XCD walks a contiguous range of row tiles (n fastest)
+    const int tiles = g.tiles_m * g.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int cpx = tiles >> 3, rem = tiles & 7;
+        const int xcd = tile & 7, slot = tile >> 3;
+        tile = xcd * cpx + min(xcd, rem) + slot;
+    }
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const long m0 = (long)tm * TM;
+    const int n0 = tn * BN;
+
+    if (t < TM) ea_s[t] = scale_exponent(g.a_rowmax[min(m0 + t, g.m - 1)]);
+    const int arow = t / TPR, akc = t % TPR;                 // this thread's row / k chunk of the A tile
+    const long grow = min(m0 + arow, g.m - 1);               // clamped: rows past m are computed and never stored
+    const int ea = scale_exponent(g.a_rowmax[grow]);
+
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = cor[i][j][r] = 0.f;
+
+    // ONE branch-free load path for every tile of every panel (aligned or not, full or partial): a 16-byte window per
+    // thread, its address clamped to the panel's last valid window (rows past m reuse row m-1, never stored; a window
+    // that would run past the end of the LAST row is moved back and its elements shifted into place), columns past the
+    // panel width masked to 0.  A branch around the loads would put an s_waitcnt vmcnt(0) at its join, every step.
+    typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef __attribute__((address_space(1))) const float4u gf4;
+    // byte addresses as integers; (static indices into the kernel arguments: a runtime index would make hipcc keep a
+    // private copy of the struct)
+#define LKG_PANEL(P)                                                                                                \
+    const unsigned long pa##P = reinterpret_cast<unsigned long>((P < g.n_panels) ? g.a[P] : g.a[0]);              \
+    const long ld##P = (P < g.n_panels) ? g.lda[P] : g.lda[0];                                                     \
+    const int kw##P = (P < g.n_panels) ? g.ka[P] : g.ka[0];                                                        \
+    const unsigned long rowp##P = pa##P + 4ul * (unsigned long)(grow * ld##P + akc * EPT);                          \
+    const unsigned long lastw##P = pa##P + 4ul * (unsigned long)((g.m - 1) * ld##P + kw##P - 4);
+    LKG_PANEL(0)
+    LKG_PANEL(1)
+    LKG_PANEL(2)
+#undef LKG_PANEL
+    const int n_tiles = g.ktiles_total;
+
+    float av[EPT];
+    uint4 qb0, qb1;
+    const uint4 *bsrc = reinterpret_cast<const uint4 *>(g.bp) + (long)tn * g.ktiles_total * (2 * BPL / 8) + t;
+
+    // the tile the next fetch reads: (panel, tile inside the panel) walked incrementally -- a closed form
+    // (gt >= kt1 ? ... : ...) became a lookup table in private memory
+    int f_gt = 0, f_tk = 0, f_panel = 0, f_nt = g.ktiles[0], f_kp = kw0;
+    unsigned long f_rowp = rowp0, f_lastw = lastw0;
+    float4u raw[EPT / 4];                          // the windows as loaded; shifted / masked when they are staged
+    int raw_sh[EPT / 4], raw_k0 = 0, raw_kp = 0;
+    auto fetch_tile = [&]() {
+        raw_k0 = f_tk * TK + akc * EPT;
+        raw_kp = f_kp;
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q) {
+            const unsigned long want = f_rowp + 4ul * (unsigned long)(f_tk * TK + 4 * q);
+            const unsigned long ptr = want < f_lastw ? want : f_lastw;
+            raw_sh[q] = (int)((want - ptr) >> 2);       // 0 unless the window was moved back (1..3; more = all masked)
+            raw[q] = *reinterpret_cast<gf4 *>(ptr);
+        }
+        const uint4 *src = bsrc + (long)f_gt * (2 * BPL / 8);
+        qb0 = src[0];
+        qb1 = src[BPL / 8];
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads here (sunk towards their use they lose the prefetch)
+        // advance (wave-uniform scalar bookkeeping only; past the last tile the state stays: duplicates are fetched)
+        if (f_gt + 1 < n_tiles) {
+            ++f_gt;
+            if (++f_tk == f_nt) {
+                f_tk = 0;
+                if (f_panel == 0) {
+                    f_rowp = rowp1; f_lastw = lastw1; f_kp = kw1; f_nt = g.ktiles[1];
+                } else {
+                    f_rowp = rowp2; f_lastw = lastw2; f_kp = kw2; f_nt = g.ktiles[2];
+                }
+                ++f_panel;
+            }
+        }
+    };
+    auto stage = [&](_Float16 *D) {               // registers -> LDS image of one tile
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q) {       // (here, a whole step after the load was issued: no wait on a fresh load)
+            const float4u v = raw[q];
+            const bool s1 = raw_sh[q] & 1, s2 = raw_sh[q] & 2;   // a barrel shifter of selects (no branch)
+            const float w0 = s1 ? v[1] : v[0], w1 = s1 ? v[2] : v[1], w2 = s1 ? v[3] : v[2], w3 = s1 ? 0.f : v[3];
+            const float e0 = s2 ? w2 : w0, e1 = s2 ? w3 : w1, e2 = s2 ? 0.f : w2, e3 = s2 ? 0.f : w3;
+            const int kk = raw_k0 + 4 * q;
+            av[4 * q] = kk < raw_kp ? e0 : 0.f;
+            av[4 * q + 1] = kk + 1 < raw_kp ? e1 : 0.f;
+            av[4 * q + 2] = kk + 2 < raw_kp ? e2 : 0.f;
+            av[4 * q + 3] = kk + 3 < raw_kp ? e3 : 0.f;
+        }
+        _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
+#pragma unroll
+        for (int q = 0; q < EPT; q += 4) {
+            fp16x2 h0, m0_, h1, m1;
+            split2(ldexpf(av[q], ea), ldexpf(av[q + 1], ea), h0, m0_);
+            split2(ldexpf(av[q + 2], ea), ldexpf(av[q + 3], ea), h1, m1);
+            typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+            const fp16x4 hv = {h0[0], h0[1], h1[0], h1[1]}, mv = {m0_[0], m0_[1], m1[0], m1[1]};
+            *reinterpret_cast<fp16x4 *>(pa + q) = hv;
+            *reinterpret_cast<fp16x4 *>(pa + APL + q) = mv;
+        }
+        uint4 *d = reinterpret_cast<uint4 *>(D + 2 * APL) + t;
+        d[0] = qb0;
+        d[BPL / 8] = qb1;
+    };
+    auto mma = [&](const _Float16 *S) {
+        f16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[i][pl] = frag<BN>(S + pl * APL, wm * 64 + i * 32, lane);
+                b[i][pl] = frag<BN>(S + 2 * APL + pl * BPL, wn * 64 + i * 32, lane);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], cor[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], cor[i][j], 0, 0, 0);
+    };
+
+    // One register set, one barrier per step, no branch in the loop (the accumulators never meet a control-flow join):
+    // step t: barrier (tile t is complete in buffer t & 1, nobody still reads the other one) -> split + write tile t+1
+    // into the other buffer -> re-issue the loads for tile t+2 -> fragment reads + 12 MFMAs of tile t.  Past the last
+    // tile the staged / fetched tile is a duplicate of the last one (in bounds, never read).
+    fetch_tile();
+    stage(smem);
+    fetch_tile();
+    for (int gt = 0; gt < n_tiles; ++gt) {
+        __syncthreads();
+        stage(smem + ((gt + 1) & 1) * BUF);
+        fetch_tile();
+        mma(smem + (gt & 1) * BUF);
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    if constexpr (EPI == EPI_PLAIN) {
+        float bias_v[2] = {0.f, 0.f};
+        int eb_v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            eb_v[j] = g.eb[col];
+            if (g.bias) bias_v[j] = g.bias[min(col, g.n - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (col >= g.n) continue;
+                const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
+                float *dst0 = g.c + (m0 + lr0) * g.ldc + col;
+                const bool all_rows = m0 + wm * 64 + i * 32 + 32 <= g.m;  // wave-uniform
+                float out[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const float v = fmaf(cor[i][j][r], 1.f / 2048.f, acc[i][j][r]);
+                    out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
+                }
+                if (g.beta != 0.f) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        old[r] = (all_rows || m0 + lr0 + dr < g.m) ? dst0[dr * g.ldc] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[r] = fmaf(g.beta, old[r], out[r]);
+                }
+                if (all_rows) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst0[((r & 3) + 8 * (r >> 2)) * g.ldc] = out[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (m0 + lr0 + dr < g.m) dst0[dr * g.ldc] = out[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
+            }
+    } else {
+        // gate: tile column block j = 0 holds g, j = 1 holds z of the SAME output column
+        const int d = g.n / 2;
+        const int col = (n0 >> 1) + wn * 32 + (lane & 31);
+        if (col < d) {
+            const int ebg = g.eb[n0 + wn * 64 + (lane & 31)], ebz = g.eb[n0 + wn * 64 + 32 + (lane & 31)];
+            const float bg = g.bias ? g.bias[col] : 0.f, bz = g.bias ? g.bias[d + col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
+                const bool all_rows = m0 + wm * 64 + i * 32 + 32 <= g.m;
+                float xv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1);
+                    xv[r] = g.x[row * g.ldx + col];
+                }
+                float ov[16], gv[16], zv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const int e = ea_s[lr0 + dr];
+                    const float gp = ldexpf(fmaf(cor[i][0][r], 1.f / 2048.f, acc[i][0][r]), -(e + ebg)) + bg;
+                    const float zp = ldexpf(fmaf(cor[i][1][r], 1.f / 2048.f, acc[i][1][r]), -(e + ebz)) + bz;
+                    gv[r] = tanh_fast(gp);
+                    zv[r] = sigmoid_fast(zp);
+                    ov[r] = fmaf(zv[r], gv[r] - xv[r], xv[r]);        // (1 - z) x + z g
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (all_rows || m0 + lr0 + dr < g.m) {
+                        const long row = m0 + lr0 + dr;
+                        g.c[row * g.ldc + col] = ov[r];
+                        if (g.g_out) g.g_out[row * g.ldg + col] = gv[r];
+                        if (g.z_out) g.z_out[row * g.ldz + col] = zv[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// out[i] = max_j |x[i, j]|   (accumulate: max with the value already there).  One wave per row.
+__global__ __launch_bounds__(256) void row_absmax_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                                         float *__restrict__ out, int accumulate, int vec) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float m = 0.f;
+    if (vec) {
+        const float4 *p = reinterpret_cast<const float4 *>(x + i * ldx);
+        for (int c = lane; c < d / 4; c += 64) {
+            const float4 v = p[c];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (int c = lane; c < d; c += 64) m = fmaxf(m, fabsf(x[i * ldx + c]));
+    }
+    m = wave_max(m);
+    if (lane == 0) out[i] = accumulate ? fmaxf(out[i], m) : m;
+}
+
+inline int total_ktiles(int n_panels, const int32_t *ka) {
+    int tt = 0;
+    for (int p = 0; p < n_panels; ++p) tt += (ka[p] + TK - 1) / TK;
+    return tt;
+}
+// tile width and number of column tiles: the gate's stacked columns are interleaved in blocks of 32 (g, z, g, z ...), so
+// its stacked extent is 64 per 32 output columns
+inline void geometry(int n, int epilogue, int &bn, int &tiles_n) {
+    if (epilogue == EPI_GATE) {
+        bn = 256;
+        tiles_n = ((n / 2 + 31) / 32 * 64 + bn - 1) / bn;
+    } else {
+        bn = n <= 128 ? 128 : 256;
+        tiles_n = (n + bn - 1) / bn;
+    }
+}
+
+}  // namespace
+
+extern "C" int lkg_row_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, int32_t accumulate,
+                                  void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d, "lkg_row_absmax_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x && out, "lkg_row_absmax_f32: null pointer");
+    const int vec = (d % 4 == 0 && ldx % 4 == 0 && lkg_aligned16(x)) ? 1 : 0;
+    hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)n, d,
+                       x, (long)ldx, out, accumulate, vec);
+    LKG_CHECK_LAUNCH("lkg_row_absmax_f32");
+    return LKG_OK;
+}
+
+extern "C" int64_t lkg_gemm_tall_workspace(int32_t n, int32_t n_panels, const int32_t *ka, int32_t epilogue) {
+    if (n <= 0 || n_panels <= 0 || n_panels > MAX_PANELS || !ka) return -1;
+    int bn, tiles_n;
+    geometry(n, epilogue, bn, tiles_n);
+    return (long)tiles_n * total_ktiles(n_panels, ka) * (2L * bn * TK) * 2 + (long)tiles_n * bn * 4 + 256;
+}
+
+extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
+                                 const int32_t *ka, const float *a_rowmax, int32_t n_groups, const float *const *b,
+                                 const int64_t *ldb, int32_t trans_b, float alpha, float beta, float *c, int64_t ldc,
+                                 const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
+                                 int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    LKG_REQUIRE(m >= 0 && n > 0 && n_panels >= 1 && n_panels <= MAX_PANELS, "lkg_gemm_tall_f32: bad sizes");
+    LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE, "lkg_gemm_tall_f32: unknown epilogue %d", epilogue);
+    LKG_REQUIRE(n_groups == (epilogue == EPI_GATE ? 2 : 1), "lkg_gemm_tall_f32: the gate stacks 2 weight groups, a plain "
+                "product 1");
+    if (m == 0) return LKG_OK;
+    LKG_REQUIRE(a && lda && ka && a_rowmax && b && ldb && c && workspace, "lkg_gemm_tall_f32: null pointer");
+    const int d_out = epilogue == EPI_GATE ? n / 2 : n;
+    LKG_REQUIRE(epilogue != EPI_GATE || (n % 2 == 0 && gate_x && ld_x >= d_out && beta == 0.f && alpha == 1.f),
+                "lkg_gemm_tall_f32: gate epilogue needs x, an even stacked width, alpha = 1, beta = 0");
+    LKG_REQUIRE(ldc >= d_out, "lkg_gemm_tall_f32: ldc %lld smaller than the output width %d", (long long)ldc, d_out);
+    const int64_t need = lkg_gemm_tall_workspace(n, n_panels, ka, epilogue);
+    LKG_REQUIRE(workspace_bytes >= need, "lkg_gemm_tall_f32: workspace of %lld bytes is smaller than the %lld required",
+                (long long)workspace_bytes, (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+    int bn, tiles_n;
+    geometry(n, epilogue, bn, tiles_n);
+    TallArgs g{};
+    BDesc bd{};
+    g.m = m; g.n = n; g.n_panels = n_panels;
+    bd.n_groups = n_groups; bd.n_panels = n_panels; bd.rows_per_group = d_out; bd.trans_b = trans_b;
+    bd.interleave = epilogue == EPI_GATE ? 1 : 0;
+    for (int p = 0; p < n_panels; ++p) {
+        LKG_REQUIRE(ka[p] > 0 && a[p] && lda[p] >= ka[p], "lkg_gemm_tall_f32: bad A panel %d", p);
+        g.a[p] = a[p]; g.lda[p] = lda[p]; g.ka[p] = ka[p]; g.ktiles[p] = (ka[p] + TK - 1) / TK;
+        bd.k[p] = ka[p];
+        for (int gr = 0; gr < n_groups; ++gr) {
+            const float *bp = b[gr * n_panels + p];
+            const int64_t ld = ldb[gr * n_panels + p];
+            LKG_REQUIRE(bp && ld >= (trans_b ? ka[p] : d_out), "lkg_gemm_tall_f32: bad B block (group %d, panel %d)", gr, p);
+            bd.ptr[gr][p] = bp; bd.ld[gr][p] = ld;
+        }
+    }
+    g.ktiles_total = total_ktiles(n_panels, ka);
+    g.tiles_m = (int)((m + TM - 1) / TM);
+    g.tiles_n = tiles_n;
+    LKG_REQUIRE((long)g.tiles_m * g.tiles_n < INT32_MAX, "lkg_gemm_tall_f32: too many tiles");
+    _Float16 *planes = reinterpret_cast<_Float16 *>(workspace);
+    int *eb = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) +
+                                      (long)g.tiles_n * g.ktiles_total * (2L * bn * TK) * 2);
+    const int n_stacked = g.tiles_n * bn;
+    hipLaunchKernelGGL(b_exponent_kernel, dim3((n_stacked + 127) / 128), dim3(128), 0, s, bd, n_stacked, eb);
+    if (bn == 256)
+        hipLaunchKernelGGL((b_planes_kernel<256>), dim3(g.tiles_n * g.ktiles_total), dim3(256), 0, s, bd, g.ktiles_total, eb, planes);
+    else
+        hipLaunchKernelGGL((b_planes_kernel<128>), dim3(g.tiles_n * g.ktiles_total), dim3(128), 0, s, bd, g.ktiles_total, eb, planes);
+    g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
+    g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    if (epilogue == EPI_GATE)
+        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_GATE>), grid, dim3(512), 0, s, g);
+    else if (bn == 256)
+        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_PLAIN>), grid, dim3(512), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_tall_kernel<128, EPI_PLAIN>), grid, dim3(256), 0, s, g);
+    LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
+    return LKG_OK;
+}

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
                                                               const float *__restrict__ g_out, long ldgo,
                                                               float *__restrict__ g_x, long ldgx,
                                                               float *__restrict__ g_gpre, long ldgg,
-                                                              float *__restrict__ g_zpre, long ldgz) {
+                                                              float *__restrict__ g_zpre, long ldgz, int activated) {
     const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
     const int c0 = (threadIdx.x & (tpr - 1)) * W;
     for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
             }
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                const float s = sigmoid_fast(zv[k]);
-                const float tg = tanh_fast(gv[k]);
+                // activated: gpre / zpre hold tanh(g) / sigmoid(z) as the fused gate epilogue kept them
+                const float s = activated ? zv[k] : sigmoid_fast(zv[k]);
+                const float tg = activated ? gv[k] : tanh_fast(gv[k]);
                 ox[k] = go[k] * (1.f - s);
                 og[k] = go[k] * s * (1.f - tg * tg);
                 oz[k] = go[k] * (tg - xv[k]) * s * (1.f - s);
@@ -416,7 +417,7 @@ extern "C" int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int6
 extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                                       int64_t ldg, const float *zpre, int64_t ldz, const float *g_out, int64_t ldgo,
                                       float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg, float *g_zpre,
-                                      int64_t ldgz, void *stream) {
+                                      int64_t ldgz, int32_t activated, void *stream) {
     LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldg >= d && ldz >= d && ldgo >= d && ldgx >= d && ldgg >= d && ldgz >= d,
                 "lkg_gate_blend_bwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
@@ -429,11 +430,11 @@ extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int6
     if (vec)
         hipLaunchKernelGGL(gate_blend_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
                            d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
-                           g_gpre, (long)ldgg, g_zpre, (long)ldgz);
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated);
     else
         hipLaunchKernelGGL(gate_blend_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
                            d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
-                           g_gpre, (long)ldgg, g_zpre, (long)ldgz);
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated);
     LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_f32");
     return LKG_OK;
 }

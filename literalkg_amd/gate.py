@@ -27,6 +27,10 @@ class GateMul(nn.Module):
     def forward(self, x_ent, x_lit_num, x_lit_txt, out=None):
         d, n = self.emb_size, self.num_lit_size
         wg = self.g.weight
+        if ops.gate_fusable(x_ent, (x_lit_num, x_lit_txt), d):     # one launch: stacked projections + blend epilogue
+            return ops.fused_gate(x_ent, (x_lit_num, x_lit_txt), (wg[:, :d], wg[:, d:d + n], wg[:, d + n:]),
+                                  (self.gate_ent.weight, self.gate_num_lit.weight, self.gate_txt_lit.weight),
+                                  self.g.bias, self.gate_bias, out)
         gpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt), (wg[:, :d], wg[:, d:d + n], wg[:, d + n:]),
                                 self.g.bias)
         zpre = ops.multi_linear((x_ent, x_lit_num, x_lit_txt),
@@ -49,6 +53,9 @@ class Gate(nn.Module):
     def forward(self, x_ent, x_lit, out=None):
         d = self.emb_size
         wg = self.g.weight
+        if ops.gate_fusable(x_ent, (x_lit,), d):
+            return ops.fused_gate(x_ent, (x_lit,), (wg[:, :d], wg[:, d:]), (self.gate_ent.weight, self.gate_lit.weight),
+                                  self.g.bias, self.gate_bias, out)
         gpre = ops.multi_linear((x_ent, x_lit), (wg[:, :d], wg[:, d:]), self.g.bias)
         zpre = ops.multi_linear((x_ent, x_lit), (self.gate_ent.weight, self.gate_lit.weight), self.gate_bias)
         return ops.gate_blend(x_ent, gpre, zpre, out)

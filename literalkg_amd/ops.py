@@ -134,15 +134,111 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         if beta != 0.0:
             raise ValueError("gemm: beta != 0 needs out")
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if not trans_a and k > 0 and tall_ok(m, n, (k,)):
+        return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
+    if _ENGINE == "f32" and not _f32_only_env():
+        raise RuntimeError("LKG_GEMM_ENGINE=f32 needs LKG_GEMM_F32_ONLY=1 as well (read by the library at its first call)")
     N.call("lkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, float(alpha), N.ptr(a), _ld(a), N.ptr(b), _ld(b),
            float(beta), N.ptr(out), _ld(out), N.ptr(bias), _stream())
     return out
+
+
+def _f32_only_env() -> bool:
+    return _os.environ.get("LKG_GEMM_F32_ONLY", "") == "1"
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
     x = _f32_rows(x)
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
     N.call("lkg_colsum_f32", x.shape[0], x.shape[1], N.ptr(x), _ld(x), N.ptr(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- tall GEMM (f16 x 2 engine)
+import ctypes as _C
+import os as _os
+
+TALL_MIN_ROWS = 16384          # below this a product is bound by its launch overhead: the f32-MFMA engine serves it
+_ENGINE = _os.environ.get("LKG_GEMM_ENGINE", "f16x2")      # f16x2 | bf16x3 (round-1 split engines) | f32 via lkg_gemm_f32
+_workspaces = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Per (device, stream) scratch for B's fp16 planes: kernels of one stream run in order, so it is reused."""
+    key = (device, _stream())
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = w
+    return w
+
+
+def row_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[i] = max_j |x[i, j]| (accumulate: max with what out holds): the row scale of the tall GEMM's A operand."""
+    _need_gpu(x)
+    x = _f32_rows(x)
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        accumulate = False
+    N.call("lkg_row_absmax_f32", x.shape[0], x.shape[1], N.ptr(x), _ld(x), N.ptr(out), int(accumulate), _stream())
+    return out
+
+
+def rows_absmax(panels: Sequence[torch.Tensor]) -> torch.Tensor:
+    out = None
+    for p in panels:
+        out = row_absmax(p, out, accumulate=out is not None)
+    return out
+
+
+def tall_ok(m: int, n: int, ks: Sequence[int]) -> bool:
+    return _ENGINE == "f16x2" and m >= TALL_MIN_ROWS and 1 <= len(ks) <= 3 and n * sum(ks) <= (1 << 22) and min(ks) > 0
+
+
+def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torch.Tensor]], trans_b: bool,
+              bias: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
+              out: Optional[torch.Tensor] = None, rowmax: Optional[torch.Tensor] = None, gate_x=None, keep=None):
+    """C = sum_p a_panels[p] @ op(B_p) (+ bias) for a tall A (lkg_gemm_tall_f32).  b_blocks[g][p]: block of B for row
+    group g (1 group; 2 = the gate's stacked g / z projections with the blend epilogue on gate_x) and panel p; trans_b:
+    blocks stored [n, k_p] (nn.Linear weights) else [k_p, n].  keep = (g_out, z_out) for the gate's backward."""
+    a_panels = [_f32_rows(a) for a in a_panels]
+    m = a_panels[0].shape[0]
+    ks = [a.shape[1] for a in a_panels]
+    n_groups = len(b_blocks)
+    gate = gate_x is not None
+    if gate != (n_groups == 2):
+        raise ValueError("gemm_tall: two weight groups go with the gate epilogue (and only with it)")
+    blocks = [[_f32_rows(b) for b in grp] for grp in b_blocks]
+    rows = blocks[0][0].shape[0] if trans_b else blocks[0][0].shape[1]
+    for grp in blocks:
+        if len(grp) != len(ks):
+            raise ValueError("gemm_tall: one B block per panel and group")
+        for b, k in zip(grp, ks):
+            if tuple(b.shape) != ((rows, k) if trans_b else (k, rows)):
+                raise ValueError(f"gemm_tall: B block of shape {tuple(b.shape)} does not match (rows {rows}, k {k})")
+    n = rows * n_groups
+    if rowmax is None:
+        rowmax = rows_absmax(a_panels)
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("gemm_tall: beta != 0 needs out")
+        out = torch.empty((m, rows), dtype=torch.float32, device=a_panels[0].device)
+    np_ = len(ks)
+    a_ptr = (_C.c_void_p * np_)(*[a.data_ptr() for a in a_panels])
+    a_ld = (_C.c_int64 * np_)(*[_ld(a) for a in a_panels])
+    a_k = (_C.c_int32 * np_)(*ks)
+    flat = [b for grp in blocks for b in grp]
+    b_ptr = (_C.c_void_p * len(flat))(*[b.data_ptr() for b in flat])
+    b_ld = (_C.c_int64 * len(flat))(*[_ld(b) for b in flat])
+    epi = 1 if gate else 0
+    need = N.load().lkg_gemm_tall_workspace(n, np_, a_k, epi)
+    ws = _workspace(int(need), out.device)
+    gx = _f32_rows(gate_x) if gate else None
+    g_out, z_out = keep if keep is not None else (None, None)
+    N.call("lkg_gemm_tall_f32", m, n, np_, a_ptr, a_ld, a_k, N.ptr(rowmax), n_groups, b_ptr, b_ld, int(trans_b),
+           float(alpha), float(beta), N.ptr(out), _ld(out), N.ptr(bias), epi, N.ptr(gx), _ld(gx) if gate else 0,
+           N.ptr(g_out), _ld(g_out) if g_out is not None else 0, N.ptr(z_out), _ld(z_out) if z_out is not None else 0,
+           N.ptr(ws), ws.numel(), _stream())
     return out
 
 
@@ -266,8 +362,12 @@ class _MultiLinear(Function):
         xs, ws = xw[:n_terms], xw[n_terms:]
         _need_gpu(*xs, *ws)
         y = None
-        for i, (x, w) in enumerate(zip(xs, ws)):
-            y = gemm(x, w, trans_b=True, beta=0.0 if i == 0 else 1.0, out=y, bias=bias if i == 0 else None)
+        if tall_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs]):
+            # every panel in ONE launch: the accumulators stay in registers, the inputs are read once
+            y = gemm_tall(xs, (ws,), True, bias)
+        else:
+            for i, (x, w) in enumerate(zip(xs, ws)):
+                y = gemm(x, w, trans_b=True, beta=0.0 if i == 0 else 1.0, out=y, bias=bias if i == 0 else None)
         ctx.save_for_backward(*xs, *ws)
         ctx.n_terms = n_terms
         ctx.has_bias = bias is not None
@@ -281,8 +381,15 @@ class _MultiLinear(Function):
         gy = _f32_rows(gy)
         gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[0]) else None
         gxs, gws = [], []
+        rm = None
         for i in range(n):
-            gxs.append(gemm(gy, ws[i]) if ctx.needs_input_grad[2 + i] else None)
+            if not ctx.needs_input_grad[2 + i]:
+                gxs.append(None)
+            elif tall_ok(gy.shape[0], ws[i].shape[1], (gy.shape[1],)):
+                rm = row_absmax(gy) if rm is None else rm       # one scale pass serves every data gradient
+                gxs.append(gemm_tall((gy,), ((ws[i],),), False, rowmax=rm))
+            else:
+                gxs.append(gemm(gy, ws[i]))
         for i in range(n):
             gws.append(gemm(gy, xs[i], trans_a=True) if ctx.needs_input_grad[2 + n + i] else None)
         return (gb, None, *gxs, *gws)
@@ -508,12 +615,95 @@ class _GateBlend(Function):
         n, d = x.shape
         gx, gg, gz = (torch.empty((n, d), dtype=torch.float32, device=x.device) for _ in range(3))
         N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
-               N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), _stream())
+               N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), 0, _stream())
         return gx, gg, gz, None
 
 
 def gate_blend(x, gpre, zpre, out: Optional[torch.Tensor] = None):
     return _GateBlend.apply(x, gpre, zpre, out)
+
+
+class _FusedGate(Function):
+    """The whole literal gate (gate.py:22-28 / 45-51) in ONE launch: the two projections g([x | lits]) and
+    z(x, lits) as one stacked tall GEMM over the K-panels (x, literal panels), tanh / sigmoid / blend in its epilogue,
+    the result written straight into ``out`` (a column slot of the concatenated table).  Inputs are read once; for the
+    backward only tanh(g) and sigmoid(z) are kept.
+    Backward: one blend kernel (g_x direct term, g_gpre, g_zpre side by side), ONE tall GEMM for the data gradient
+    [g_gpre | g_zpre] . [W_g[:, :d] ; W_e] accumulated onto the direct term, the weight gradients as long-k products."""
+
+    @staticmethod
+    def forward(ctx, out, bg, bz, n_lit, x, *rest):
+        lits = rest[:n_lit]
+        wgs = rest[n_lit:2 * n_lit + 1]           # g.weight column panels: [x part, literal parts ...]
+        wzs = rest[2 * n_lit + 1:]                # gate_ent.weight, gate_*_lit.weight ...
+        _need_gpu(x, *lits, *wgs, *wzs)
+        x = _f32_rows(x)
+        n, d = x.shape
+        panels = (x,) + tuple(_f32_rows(l) for l in lits)
+        if out is None:
+            out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        training = any(ctx.needs_input_grad)
+        keep = None
+        if training:
+            keep = (torch.empty((n, d), dtype=torch.float32, device=x.device),
+                    torch.empty((n, d), dtype=torch.float32, device=x.device))
+        bias = torch.cat([bg, bz]) if bg is not None else None
+        # the literals are constants of the model: their row maxima are computed once and cached on the tensor
+        rm = row_absmax(x)
+        for l in panels[1:]:
+            cached = getattr(l, "_lkg_rowmax", None)
+            if cached is None or cached[0] != l._version or cached[1].device != l.device:
+                cached = (l._version, row_absmax(l))
+                try:
+                    l._lkg_rowmax = cached
+                except AttributeError:
+                    pass
+            torch.maximum(rm, cached[1], out=rm)             # (n floats: bookkeeping, not a pass over the table)
+        gemm_tall(panels, (wgs, wzs), True, bias, out=out, rowmax=rm, gate_x=x, keep=keep)
+        ctx.n_lit = n_lit
+        ctx.has_bias = bg is not None
+        if training:
+            ctx.save_for_backward(x, keep[0], keep[1], *panels[1:], *wgs, *wzs)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        nl = ctx.n_lit
+        sv = ctx.saved_tensors
+        x, g, z = sv[0], sv[1], sv[2]
+        lits, wgs, wzs = sv[3:3 + nl], sv[3 + nl:4 + 2 * nl], sv[4 + 2 * nl:]
+        go = _f32_rows(go)
+        n, d = x.shape
+        gx = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        gpz = torch.empty((n, 2 * d), dtype=torch.float32, device=x.device)      # [g_gpre | g_zpre]
+        ggp, gzp = gpz[:, :d], gpz[:, d:]
+        N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
+               _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, _stream())
+        need = ctx.needs_input_grad           # (out, bg, bz, n_lit, x, lits..., wgs..., wzs...)
+        g_x = None
+        if need[4]:
+            if tall_ok(n, d, (d, d)):
+                g_x = gemm_tall((ggp, gzp), ((wgs[0], wzs[0]),), False, beta=1.0, out=gx)
+            else:
+                g_x = gemm(ggp, wgs[0], beta=1.0, out=gx)
+                g_x = gemm(gzp, wzs[0], beta=1.0, out=g_x)
+        gb_g = colsum(ggp) if (ctx.has_bias and need[1]) else None
+        gb_z = colsum(gzp) if (ctx.has_bias and need[2]) else None
+        panels = (x,) + tuple(lits)
+        base = 5 + nl
+        g_wg = [gemm(ggp, panels[i], trans_a=True) if need[base + i] else None for i in range(nl + 1)]
+        g_wz = [gemm(gzp, panels[i], trans_a=True) if need[base + nl + 1 + i] else None for i in range(nl + 1)]
+        return (None, gb_g, gb_z, None, g_x, *([None] * nl), *g_wg, *g_wz)
+
+
+def fused_gate(x, lits: Sequence[torch.Tensor], wg_panels: Sequence[torch.Tensor], wz_panels: Sequence[torch.Tensor],
+               bias_g, bias_z, out: Optional[torch.Tensor] = None):
+    """out = (1 - sigmoid(z)) x + sigmoid(z) tanh(g),  g = [x | lits] wg^T + bias_g,  z = x wz_0^T + sum lits wz_i^T + bias_z"""
+    return _FusedGate.apply(out, bias_g, bias_z, len(lits), x, *lits, *wg_panels, *wz_panels)
+
+
+def gate_fusable(x, lits, d) -> bool:
+    return tall_ok(x.shape[0], 2 * d, [x.shape[1]] + [l.shape[1] for l in lits])
 
 
 # ----------------------------------------------------------------------------- K8 TransE scoring

@@ -277,6 +277,92 @@ def test_gemm_weight_gradient_engine_is_f32_accurate(ops, gpu_device, m, n, k):
     torch.testing.assert_close(head.double(), want_head, rtol=1e-5, atol=2e-6 * float(want_head.abs().max()))
 
 
+@pytest.mark.parametrize("ks,n,tb", [((256,), 256, True), ((256, 2, 300), 256, True), ((64, 64), 128, True), ((30, 7), 50, True),
+                                     ((256,), 256, False), ((512,), 300, True), ((3,), 5, False), ((128, 128), 64, False)])
+def test_gemm_tall_f16x2_engine_is_f32_accurate(ops, gpu_device, ks, n, tb):
+    """lkg_gemm_tall_f32 (row-scaled fp16 hi/mid split, 3 MFMAs per product): against f64 it is within a small factor
+    of an f32 GEMM's own rounding error -- multi-panel A from different arrays, unaligned / odd widths, edge tiles,
+    alpha / beta / bias -- and rows spanning 60 orders of magnitude keep that accuracy relative to their own scale."""
+    gen = torch.Generator().manual_seed(sum(ks) * 1000 + n)
+    m = 16384 + 77
+    panels = [torch.randn(m, k + 3, generator=gen)[:, 3:].to(gpu_device) if i % 2 else torch.randn(m, k, generator=gen).to(gpu_device)
+              for i, k in enumerate(ks)]
+    blocks = [(torch.randn((n, k) if tb else (k, n), generator=gen) * 0.1).to(gpu_device) for k in ks]
+    a64 = torch.cat([p.double() for p in panels], 1)
+    b64 = torch.cat([b.double() if tb else b.double().t() for b in blocks], 1)          # [n, K]
+    want = a64 @ b64.t()
+    scale = float(want.abs().max())
+    got = ops.gemm_tall(panels, (blocks,), tb)
+    err = float((got.double() - want).abs().max()) / scale
+    f32 = float(((a64.float() @ b64.float().t()).double() - want).abs().max()) / scale
+    assert err <= max(3.0 * f32, 1e-6), (err, f32)
+    bias = torch.randn(n, generator=gen).to(gpu_device)
+    c0 = torch.randn(m, n + 5, generator=gen).to(gpu_device)[:, 5:]                     # strided output
+    got2 = ops.gemm_tall(panels, (blocks,), tb, bias, alpha=0.5, beta=2.0, out=c0.clone())
+    torch.testing.assert_close(got2.double(), 0.5 * want + 2.0 * c0.double() + bias.double(), rtol=1e-5,
+                               atol=4e-6 * scale)
+    # per-row dynamic range: every row is accurate relative to ITS OWN magnitude (power-of-two row scaling)
+    exps = torch.randint(-30, 30, (m, 1), generator=gen).float()
+    mags = torch.pow(torch.tensor(10.0), exps).to(gpu_device)
+    mags[5] = 0.0                                                                       # an all-zero row
+    scaled = [p * mags for p in panels]
+    got3 = ops.gemm_tall(scaled, (blocks,), tb)
+    want3 = torch.cat([p.double() for p in scaled], 1) @ b64.t()
+    row_scale = want3.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    rel = ((got3.double() - want3).abs() / row_scale)
+    assert float(rel.max()) <= max(30.0 * f32, 1e-5), float(rel.max())
+    assert float(got3[5].abs().max()) == 0.0
+    # one huge element in a row of small ones: the small ones keep ~f32 accuracy (22 bits down to 2^-27 of the row max)
+    spiky = [p.clone() for p in panels]
+    spiky[0][:, 0] = 3000.0
+    blocks0 = [b.clone() for b in blocks]
+    if tb:
+        blocks0[0][:, 0] = 0.0
+    else:
+        blocks0[0][0, :] = 0.0                                                          # the spike meets a zero weight
+    got4 = ops.gemm_tall(spiky, (blocks0,), tb)
+    b0 = torch.cat([b.double() if tb else b.double().t() for b in blocks0], 1)
+    want4 = torch.cat([p.double() for p in spiky], 1) @ b0.t()
+    err4 = float((got4.double() - want4).abs().max()) / float(want4.abs().max())
+    assert err4 <= max(10.0 * f32, 5e-6), (err4, f32)
+
+
+def test_fused_gate_matches_oracle_and_the_unfused_path(L, ops, O, gpu_device):
+    """GateMul / Gate through the one-launch stacked GEMM with the blend epilogue (rows >= 16384) against the oracle's
+    gate (forward, input gradient, every weight gradient), with literal widths that are not multiples of 4."""
+    torch.manual_seed(2)
+    n = 16384 + 333
+    for d, nn_, nt in ((64, 2, 300), (48, 3, 7), (256, 2, 20)):
+        gate = L.GateMul(d, nn_, nt).to(gpu_device)
+        x = (torch.randn(n, d) * 0.5).to(gpu_device).requires_grad_(True)
+        num, txt = torch.rand(n, nn_).to(gpu_device), torch.randn(n, nt).to(gpu_device)
+        assert ops.gate_fusable(x, (num, txt), d)
+        out = gate(x, num, txt)
+        w = torch.randn(n, d, device=gpu_device)
+        (out * w).sum().backward()
+        p = {("emb_mul_lit." + k): v.detach().cpu().clone().requires_grad_(True) for k, v in gate.state_dict().items()}
+        xc = x.detach().cpu().clone().requires_grad_(True)
+        ref = O.gate_mul(p, "emb_mul_lit.", xc, num.cpu(), txt.cpu())
+        (ref * w.cpu()).sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(x.grad.cpu(), xc.grad, rtol=1e-4, atol=1e-5)
+        for k, v in gate.named_parameters():
+            ref_g = p["emb_mul_lit." + k].grad
+            err = float((v.grad.cpu() - ref_g).abs().max()) / (float(ref_g.abs().max()) + 1e-12)
+            assert err < 1e-4, (d, k, err)
+    # single-literal gate, written into a column slot of a wider buffer
+    gate = L.Gate(32, 5).to(gpu_device)
+    x = (torch.randn(n, 32) * 0.5).to(gpu_device)
+    lit = torch.randn(n, 5).to(gpu_device)
+    buf = torch.zeros(n, 96, device=gpu_device)
+    with torch.no_grad():
+        out = gate(x, lit, buf[:, 32:64])
+    p = {("g." + k): v.detach().cpu() for k, v in gate.state_dict().items()}
+    ref = O.gate_single(p, "g.", x.cpu(), lit.cpu())
+    torch.testing.assert_close(buf[:, 32:64].cpu(), ref, rtol=1e-5, atol=2e-6)
+    assert float(buf[:, :32].abs().max()) == 0.0 and float(buf[:, 64:].abs().max()) == 0.0
+
+
 def test_gemm_full_size_products_of_the_dense_layer(ops, gpu_device):
     """The three products of one nn.Linear at the BASELINE shape (1 M rows, 256 x 256): every row tile of the forward
     and the data gradient is checked on a strided row sample against f64, the weight gradient as a whole."""
