@@ -136,15 +136,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if not trans_a and k > 0 and tall_ok(m, n, (k,)):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
-    if _ENGINE == "f32" and not _f32_only_env():
-        raise RuntimeError("LKG_GEMM_ENGINE=f32 needs LKG_GEMM_F32_ONLY=1 as well (read by the library at its first call)")
     N.call("lkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, float(alpha), N.ptr(a), _ld(a), N.ptr(b), _ld(b),
            float(beta), N.ptr(out), _ld(out), N.ptr(bias), _stream())
     return out
 
-
-def _f32_only_env() -> bool:
-    return _os.environ.get("LKG_GEMM_F32_ONLY", "") == "1"
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
@@ -191,8 +186,16 @@ def rows_absmax(panels: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def tall_ok(m: int, n: int, ks: Sequence[int]) -> bool:
-    return _ENGINE == "f16x2" and m >= TALL_MIN_ROWS and 1 <= len(ks) <= 3 and n * sum(ks) <= (1 << 22) and min(ks) > 0
+def tall_ok(m: int, n: int, ks: Sequence[int], single_panel_too: bool = False) -> bool:
+    """The tall engine takes the products whose inputs it reads ONCE where the round-1 engines need several
+    accumulating launches: multi-panel Linears and the fused gate.  A plain one-panel product stays on the bf16 x 3
+    engine of lkg_gemm_f32 (measured at 1 M x 256 x 256: 0.84 ms there, 0.72 ms + a 0.19 ms row-scale pass here) unless
+    LKG_GEMM_ENGINE=f16x2-all asks for it."""
+    if _ENGINE not in ("f16x2", "f16x2-all") or m < TALL_MIN_ROWS or not 1 <= len(ks) <= 3 or min(ks) <= 0:
+        return False
+    if len(ks) == 1 and not (single_panel_too or _ENGINE == "f16x2-all"):
+        return False
+    return n * sum(ks) <= (1 << 22)
 
 
 def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torch.Tensor]], trans_b: bool,

@@ -19,7 +19,7 @@ w = torch.randn(d, d, device=dev) * 0.06; b = torch.randn(d, device=dev)
 out = torch.empty(n, d, device=dev)
 rm = ops.row_absmax(x)
 print(f"row_absmax {n}x{d}: {tm(lambda: ops.row_absmax(x, rm)):.3f} ms")
-for eng in ("f16x2", "bf16x3"):
+for eng in ("f16x2-all", "bf16x3"):
     ops._ENGINE = eng
     f = tm(lambda: ops.gemm(x, w, trans_b=True, bias=b, out=out))
     g = tm(lambda: ops.gemm(gy, w, out=out))
