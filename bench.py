@@ -185,9 +185,22 @@ def gate_timing(n, d, dev):
         ms = _timed(lambda: gate(x, num, txt, out))
     flops = 2.0 * n * (d + 302) * d * 2
     alg = 4.0 * n * (d + 302 + d)
-    return {"kernel": f"GateMul forward {n} x ({d}+2+300) -> {d}", "ms": ms,
-            "tflops_f32_equivalent": flops / ms / 1e9, "frac_of_bf16x3_peak": flops / ms / 1e9 / (2500.0 / 6),
-            "algorithmic_bytes": alg, "algorithmic_GBs": alg / ms / 1e6}
+    traffic, src = None, "no PMC summary committed"
+    rec_path = os.path.join(ROOT, "profiles", "r02_gate_pmc_traffic.json")
+    if os.path.exists(rec_path):          # counter-measured HBM bytes of this launch, valid for THIS kernel source only
+        rec = json.load(open(rec_path))
+        sha = source_sha(os.path.join(ROOT, "literalkg_amd", "csrc", "lkg_gemm_tall.hip"))
+        if rec.get("tall_source_sha16") == sha and abs(rec.get("algorithmic_bytes", 0) - alg) < 1:
+            traffic, src = rec["traffic_bytes"], os.path.relpath(rec_path, ROOT)
+        else:
+            src = f"{os.path.relpath(rec_path, ROOT)} was taken on another lkg_gemm_tall.hip or shape"
+    return {"kernel": f"GateMul forward {n} x ({d}+2+300) -> {d}: ONE launch of gemm_tall_kernel (f32 product as 3 "
+                      f"v_mfma_f32_32x32x16_f16 per 16 k on a row-scaled exact fp16 hi/mid split, blend epilogue)",
+            "ms": ms, "tflops_f32_equivalent": flops / ms / 1e9,
+            "mfma_pipe_frac": 3 * flops / ms / 1e9 / 2500.0,
+            "algorithmic_bytes": alg, "algorithmic_GBs": alg / ms / 1e6, "frac_of_hbm_roofline": alg / ms / 1e6 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "traffic_over_algorithmic": (traffic / alg) if traffic else None}
 
 
 def sharded_step_timings(world, rank, dev, n_glob, d, h_own, t_own, r_own, steps):

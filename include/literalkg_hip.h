@@ -393,7 +393,8 @@ int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t
  *                      stored [rows][ka[p]] (an nn.Linear weight or a column slice of one), 0: stored [ka[p]][rows]
  *                      (the data gradient  gy . W).  n_groups = 1: rows = n.  Epilogue 1 (gate): n_groups = 2 row
  *                      groups of n / 2 (the g and the z projection of gate.py:22-25), bias = [b_g | b_z], and
- *                      C[m, n/2] = (1 - sigmoid(z)) gate_x + sigmoid(z) tanh(g)   (gate.py:26) with tanh(g) / sigmoid(z)
+ *                      C[m, n/2] = (1 - sigmoid(z)) gate_x + sigmoid(z) tanh(g)   (gate.py:26; gate_x IS the first K-panel, a[0] --
+ *                      its values are kept on chip while they pass through the staging registers) with tanh(g) / sigmoid(z)
  *                      optionally kept in gate_g / gate_z for lkg_gate_blend_bwd_f32(activated = 1);
  *   epilogue 0         C = alpha * product + beta * C + bias[n];
  *   workspace          >= lkg_gemm_tall_workspace(n, n_panels, ka, epilogue) bytes (B's fp16 planes: no allocation here). */

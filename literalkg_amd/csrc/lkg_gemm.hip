@@ -421,12 +421,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA], b[1][PB], acc[0][1], 0, 0, 0);            \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[0][PB], acc[1][0], 0, 0, 0);            \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA], b[1][PB], acc[1][1], 0, 0, 0);
-        auto stage = [&](__bf16(*D)[3 * PLANE]) {
-            bf16x8 pa[3], pb[3];
-            split_planes(la.v, pa);
-            split_planes(lb.v, pb);
-            kmajor_store(pa, D[0], t);
-            kmajor_store(pb, D[1], t);
+        auto stage = [&](__bf16(*D)[3 * PLANE]) {      // one operand at a time: its three planes are dead before the next split
+            {
+                bf16x8 pa[3];
+                split_planes(la.v, pa);
+                kmajor_store(pa, D[0], t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 pb[3];
+                split_planes(lb.v, pb);
+                kmajor_store(pb, D[1], t);
+            }
         };
         auto mma = [&](const __bf16(*S)[3 * PLANE]) {
             bf16x8 a[2][3], b[2][3];

@@ -158,8 +158,12 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int TPR = TK / EPT;                 // threads per A row
     constexpr int APL = TM * TK, BPL = BN * TK;   // halves per plane
     constexpr int BUF = 2 * APL + 2 * BPL;        // halves per buffer
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BUF + 2 * TM];   // (one object: planes, then the row exponents)
+    // ONE dynamic LDS object: staging planes, the tile's row exponents, and (gate) the stash of the x values the blend
+    // needs -- x is the gate's first K-panel, so the columns of this tile pass through the staging registers anyway
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     int *ea_s = reinterpret_cast<int *>(smem + 2 * BUF);
+    constexpr int XP = 132;                        // stash pitch (floats): 128 columns + 4, conflict-free 16-byte writes
+    float *xstash = reinterpret_cast<float *>(smem + 2 * BUF + 2 * TM);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / (BN / 64), wn = wave % (BN / 64);
@@ -218,9 +222,11 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     unsigned long f_rowp = rowp0, f_lastw = lastw0;
     float4u raw[EPT / 4];                          // the windows as loaded; shifted / masked when they are staged
     int raw_sh[EPT / 4], raw_k0 = 0, raw_kp = 0;
+    bool raw_first = true;                         // the staged tile belongs to panel 0
     auto fetch_tile = [&]() {
         raw_k0 = f_tk * TK + akc * EPT;
         raw_kp = f_kp;
+        raw_first = f_panel == 0;
 #pragma unroll
         for (int q = 0; q < EPT / 4; ++q) {
             const unsigned long want = f_rowp + 4ul * (unsigned long)(f_tk * TK + 4 * q);
@@ -258,6 +264,11 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             av[4 * q + 1] = kk + 1 < raw_kp ? e1 : 0.f;
             av[4 * q + 2] = kk + 2 < raw_kp ? e2 : 0.f;
             av[4 * q + 3] = kk + 3 < raw_kp ? e3 : 0.f;
+        }
+        if constexpr (EPI == EPI_GATE) {          // keep x[rows of the tile, output columns of the tile] for the epilogue
+            const int c = raw_k0 - (n0 >> 1);     // (EPT = 4 at BN = 256)
+            if (raw_first && c >= 0 && c < 128)
+                *reinterpret_cast<float4 *>(xstash + arow * XP + c) = make_float4(av[0], av[1], av[2], av[3]);
         }
         _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
 #pragma unroll
@@ -311,7 +322,40 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mma(smem + (gt & 1) * BUF);
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
+    // holds ONE column of 16 rows.  Written as it stands that is 16 dword stores per tile (two 128-byte runs per
+    // instruction); instead every wave turns its tile through a private 4 KB of the (now free) staging LDS and stores
+    // 16 bytes per lane, 8 rows x 128 B per instruction -- 4 stores per tile.
+    __syncthreads();                                           // every wave is done reading the staging buffers
+    float *ts = reinterpret_cast<float *>(smem) + wave * 1024;
+    auto put = [&](const float(&v)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ts[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[r];
+    };
+    // rows row0 .. row0 + 31 (global), columns col0 .. col0 + 31 of `base` (n_cols wide): out = ts (+ beta * old)
+    auto flush = [&](float *base, long ld, long row0, int col0, int n_cols, float beta) {
+        const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        const int col = col0 + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long row = row0 + 8 * q + (lane >> 3);
+            float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+            if (row >= g.m) continue;
+            float *dst = base + row * ld + col;
+            if (vec && col + 3 < n_cols) {
+                if (beta != 0.f) {
+                    const float4 o = *reinterpret_cast<const float4 *>(dst);
+                    v.x = fmaf(beta, o.x, v.x); v.y = fmaf(beta, o.y, v.y); v.z = fmaf(beta, o.z, v.z); v.w = fmaf(beta, o.w, v.w);
+                }
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (col + k < n_cols) dst[k] = beta != 0.f ? fmaf(beta, dst[k], e[k]) : e[k];
+            }
+        }
+    };
     if constexpr (EPI == EPI_PLAIN) {
         float bias_v[2] = {0.f, 0.f};
         int eb_v[2];
@@ -325,11 +369,9 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-                if (col >= g.n) continue;
+                const int col0 = n0 + wn * 64 + j * 32;
+                if (col0 >= g.n) continue;                                // wave-uniform
                 const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
-                float *dst0 = g.c + (m0 + lr0) * g.ldc + col;
-                const bool all_rows = m0 + wm * 64 + i * 32 + 32 <= g.m;  // wave-uniform
                 float out[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -337,45 +379,25 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const float v = fmaf(cor[i][j][r], 1.f / 2048.f, acc[i][j][r]);
                     out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
                 }
-                if (g.beta != 0.f) {
-                    float old[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        old[r] = (all_rows || m0 + lr0 + dr < g.m) ? dst0[dr * g.ldc] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) out[r] = fmaf(g.beta, old[r], out[r]);
-                }
-                if (all_rows) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dst0[((r & 3) + 8 * (r >> 2)) * g.ldc] = out[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        if (m0 + lr0 + dr < g.m) dst0[dr * g.ldc] = out[r];
-                    }
-                }
+                put(out);
+                flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
                 __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
             }
     } else {
         // gate: tile column block j = 0 holds g, j = 1 holds z of the SAME output column
         const int d = g.n / 2;
-        const int col = (n0 >> 1) + wn * 32 + (lane & 31);
-        if (col < d) {
+        const int col0 = (n0 >> 1) + wn * 32;
+        const int col = col0 + (lane & 31);
+        if (col0 < d) {                                                   // wave-uniform
+            const int cc = min(col, d - 1);                               // lanes past d compute on a clamped column, never stored
             const int ebg = g.eb[n0 + wn * 64 + (lane & 31)], ebz = g.eb[n0 + wn * 64 + 32 + (lane & 31)];
-            const float bg = g.bias ? g.bias[col] : 0.f, bz = g.bias ? g.bias[d + col] : 0.f;
+            const float bg = g.bias ? g.bias[cc] : 0.f, bz = g.bias ? g.bias[d + cc] : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
-                const bool all_rows = m0 + wm * 64 + i * 32 + 32 <= g.m;
                 float xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1);
-                    xv[r] = g.x[row * g.ldx + col];
-                }
+                for (int r = 0; r < 16; ++r) xv[r] = xstash[(lr0 + (r & 3) + 8 * (r >> 2)) * XP + wn * 32 + (lane & 31)];
                 float ov[16], gv[16], zv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -387,15 +409,16 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     zv[r] = sigmoid_fast(zp);
                     ov[r] = fmaf(zv[r], gv[r] - xv[r], xv[r]);        // (1 - z) x + z g
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (all_rows || m0 + lr0 + dr < g.m) {
-                        const long row = m0 + lr0 + dr;
-                        g.c[row * g.ldc + col] = ov[r];
-                        if (g.g_out) g.g_out[row * g.ldg + col] = gv[r];
-                        if (g.z_out) g.z_out[row * g.ldz + col] = zv[r];
-                    }
+                const long row0 = m0 + wm * 64 + i * 32;
+                put(ov);
+                flush(g.c, g.ldc, row0, col0, d, 0.f);
+                if (g.g_out) {
+                    put(gv);
+                    flush(g.g_out, g.ldg, row0, col0, d, 0.f);
+                }
+                if (g.z_out) {
+                    put(zv);
+                    flush(g.z_out, g.ldz, row0, col0, d, 0.f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -476,6 +499,8 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     const int d_out = epilogue == EPI_GATE ? n / 2 : n;
     LKG_REQUIRE(epilogue != EPI_GATE || (n % 2 == 0 && gate_x && ld_x >= d_out && beta == 0.f && alpha == 1.f),
                 "lkg_gemm_tall_f32: gate epilogue needs x, an even stacked width, alpha = 1, beta = 0");
+    LKG_REQUIRE(epilogue != EPI_GATE || (gate_x == a[0] && ld_x == lda[0] && ka[0] == d_out),
+                "lkg_gemm_tall_f32: the gate blends its FIRST K-panel (gate_x must be a[0], %d wide)", d_out);
     LKG_REQUIRE(ldc >= d_out, "lkg_gemm_tall_f32: ldc %lld smaller than the output width %d", (long long)ldc, d_out);
     const int64_t need = lkg_gemm_tall_workspace(n, n_panels, ka, epilogue);
     LKG_REQUIRE(workspace_bytes >= need, "lkg_gemm_tall_f32: workspace of %lld bytes is smaller than the %lld required",
@@ -515,12 +540,24 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    auto lds_bytes = [](int bn_, bool gate) {
+        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + TM * 4 + (gate ? TM * 132 * 4 : 0);
+    };
+    static bool lds_raised = false;
+    if (!lds_raised) {       // the gate variant needs 117 KB of dynamic LDS (default limit 64 KB)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<256, EPI_GATE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256, true)) != hipSuccess) {
+            lkg_set_error("lkg_gemm_tall_f32: cannot raise the dynamic LDS limit");
+            return LKG_ERR_HIP;
+        }
+        lds_raised = true;
+    }
     if (epilogue == EPI_GATE)
-        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_GATE>), grid, dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_GATE>), grid, dim3(512), lds_bytes(256, true), s, g);
     else if (bn == 256)
-        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_PLAIN>), grid, dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_PLAIN>), grid, dim3(512), lds_bytes(256, false), s, g);
     else
-        hipLaunchKernelGGL((gemm_tall_kernel<128, EPI_PLAIN>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_tall_kernel<128, EPI_PLAIN>), grid, dim3(256), lds_bytes(128, false), s, g);
     LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
     return LKG_OK;
 }

@@ -635,7 +635,7 @@ class _FusedGate(Function):
     [g_gpre | g_zpre] . [W_g[:, :d] ; W_e] accumulated onto the direct term, the weight gradients as long-k products."""
 
     @staticmethod
-    def forward(ctx, out, bg, bz, n_lit, x, *rest):
+    def forward(ctx, out, bg, bz, n_lit, grad_mode, x, *rest):
         lits = rest[:n_lit]
         wgs = rest[n_lit:2 * n_lit + 1]           # g.weight column panels: [x part, literal parts ...]
         wzs = rest[2 * n_lit + 1:]                # gate_ent.weight, gate_*_lit.weight ...
@@ -645,7 +645,7 @@ class _FusedGate(Function):
         panels = (x,) + tuple(_f32_rows(l) for l in lits)
         if out is None:
             out = torch.empty((n, d), dtype=torch.float32, device=x.device)
-        training = any(ctx.needs_input_grad)
+        training = grad_mode and any(ctx.needs_input_grad)     # (needs_input_grad ignores no_grad; forward runs with grad off)
         keep = None
         if training:
             keep = (torch.empty((n, d), dtype=torch.float32, device=x.device),
@@ -682,9 +682,9 @@ class _FusedGate(Function):
         ggp, gzp = gpz[:, :d], gpz[:, d:]
         N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
                _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, _stream())
-        need = ctx.needs_input_grad           # (out, bg, bz, n_lit, x, lits..., wgs..., wzs...)
+        need = ctx.needs_input_grad           # (out, bg, bz, n_lit, grad_mode, x, lits..., wgs..., wzs...)
         g_x = None
-        if need[4]:
+        if need[5]:
             if tall_ok(n, d, (d, d)):
                 g_x = gemm_tall((ggp, gzp), ((wgs[0], wzs[0]),), False, beta=1.0, out=gx)
             else:
@@ -693,16 +693,16 @@ class _FusedGate(Function):
         gb_g = colsum(ggp) if (ctx.has_bias and need[1]) else None
         gb_z = colsum(gzp) if (ctx.has_bias and need[2]) else None
         panels = (x,) + tuple(lits)
-        base = 5 + nl
+        base = 6 + nl
         g_wg = [gemm(ggp, panels[i], trans_a=True) if need[base + i] else None for i in range(nl + 1)]
         g_wz = [gemm(gzp, panels[i], trans_a=True) if need[base + nl + 1 + i] else None for i in range(nl + 1)]
-        return (None, gb_g, gb_z, None, g_x, *([None] * nl), *g_wg, *g_wz)
+        return (None, gb_g, gb_z, None, None, g_x, *([None] * nl), *g_wg, *g_wz)
 
 
 def fused_gate(x, lits: Sequence[torch.Tensor], wg_panels: Sequence[torch.Tensor], wz_panels: Sequence[torch.Tensor],
                bias_g, bias_z, out: Optional[torch.Tensor] = None):
     """out = (1 - sigmoid(z)) x + sigmoid(z) tanh(g),  g = [x | lits] wg^T + bias_g,  z = x wz_0^T + sum lits wz_i^T + bias_z"""
-    return _FusedGate.apply(out, bias_g, bias_z, len(lits), x, *lits, *wg_panels, *wz_panels)
+    return _FusedGate.apply(out, bias_g, bias_z, len(lits), torch.is_grad_enabled(), x, *lits, *wg_panels, *wz_panels)
 
 
 def gate_fusable(x, lits, d) -> bool:

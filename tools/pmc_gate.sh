@@ -1,0 +1,26 @@
+#!/bin/bash
+# HBM traffic of the fused gate launch (gemm_tall_kernel<256, 1>): separate FETCH_SIZE / WRITE_SIZE passes, corrected as
+# MI355X_MICROARCH.md prescribes, written as a profiles/-shaped JSON.   usage: tools/pmc_gate.sh <outdir>
+out=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p $out
+timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 tools/gate_only.py > /dev/null 2> $out/fetch.err || exit 1
+timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 tools/gate_only.py > /dev/null 2> $out/write.err || exit 2
+python3 - <<PY
+import csv, glob, hashlib, json
+def vals(d, name):
+    f = glob.glob(f"$out/{d}/**/*counter_collection.csv", recursive=True)[0]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_tall_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+fe, wr = vals("fetch", "FETCH_SIZE"), vals("write", "WRITE_SIZE")
+fe, wr = fe[1:], wr[1:]                       # first launch: cold
+n, d = 1_000_000, 256
+alg = 4.0 * n * (d + 302 + d)
+mean = lambda x: sum(x) / len(x)
+rec = {"kernel": "gemm_tall_kernel<256, gate epilogue>: GateMul forward 1000000 x (256+2+300) -> 256, eval (no g/z kept)",
+       "tall_source_sha16": hashlib.sha256(open("literalkg_amd/csrc/lkg_gemm_tall.hip", "rb").read()).hexdigest()[:16],
+       "launches_sampled": len(fe), "FETCH_SIZE_KiB": mean(fe), "WRITE_SIZE_KiB": mean(wr),
+       "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+       "traffic_bytes": (2 * mean(fe) + mean(wr)) * 1024, "algorithmic_bytes": alg}
+rec["traffic_over_algorithmic"] = rec["traffic_bytes"] / alg
+print(json.dumps(rec, indent=1))
+PY
