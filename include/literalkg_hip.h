@@ -367,15 +367,17 @@ int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg
  * Engines (chosen from the shape, results agree to f32 rounding): the f32-input MFMA (v_mfma_f32_32x32x2_f32), and two
  * "bf16 x 3" engines that form the f32 product from six v_mfma_f32_32x32x16_bf16 over an exact three-way bf16 split
  * of every operand (A row-major with m >= 16384 and a small B -- Linear forward / data gradient; trans_a = 1,
- * trans_b = 0 with k >= 2048 -- weight gradients).  The first allocates a stream-ordered workspace of
- * 6 * ceil(n/128)*128 * ceil(k/16)*16 bytes with hipMallocAsync on `stream` and frees it with hipFreeAsync.
+ * trans_b = 0 with k >= 2048 -- weight gradients).  The first needs lkg_gemm_workspace(trans_a, m, n, k) bytes of
+ * caller-provided device workspace for B's planes (0 = the engine does not apply to this shape); without it (NULL or
+ * too small) the product runs on the f32-input MFMA.  No allocation inside.
  * LKG_GEMM_F32_ONLY=1 in the environment (read at the first call) keeps every product on the f32-input MFMA.
  * trans_a / trans_b: 0 = stored as written, 1 = stored transposed (A is k x m / B is n x k).
  * Used for nn.Linear forward (trans_b = 1), its data gradient and its weight
  * gradient (model.py:111 etc., gate.py:24-25, linear_gat model.py:309).          */
+int64_t lkg_gemm_workspace(int32_t trans_a, int64_t m, int64_t n, int64_t k);
 int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
-                 int64_t ldc, const float *bias, void *stream);
+                 int64_t ldc, const float *bias, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Tall GEMM of the layers' dense part (lkg_gemm_tall.hip): m rows (entities), n <= a few hundred output columns,
  *   C[m, n] = epilogue( sum over K-panels p of  A_p[m, ka[p]] . B_p[n, ka[p]]^T )            f32 in, f32 out.

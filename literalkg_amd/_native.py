@@ -60,13 +60,14 @@ PROTOTYPES = {
     "lkg_gemm_tall_workspace": [i32, i32, vp, i32],
     "lkg_gemm_tall_f32": [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, i64, vp, i32, vp, i64, vp, i64,
                           vp, i64, vp, i64, vp],
-    "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp],
+    "lkg_gemm_workspace": [i32, i64, i64, i64],
+    "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i64, vp],
     "lkg_colsum_f32": [i64, i32, vp, i64, vp, vp],
     "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],
     "lkg_adam_step_f32": [i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp],
 }
 _RESTYPE = {"lkg_last_error": C.c_char_p, "lkg_csr_build_device_workspace": C.c_int64,
-            "lkg_gemm_tall_workspace": C.c_int64,
+            "lkg_gemm_tall_workspace": C.c_int64, "lkg_gemm_workspace": C.c_int64,
             "lkg_csr_transpose_device_workspace": C.c_int64}
 
 

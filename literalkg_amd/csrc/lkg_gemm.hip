@@ -599,9 +599,17 @@ int run(bool ta, bool tb, const GemmArgs &g, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+// bytes of workspace with which lkg_gemm_f32 can run this product on split engine 1 (0: the engine does not apply)
+extern "C" int64_t lkg_gemm_workspace(int32_t trans_a, int64_t m, int64_t n, int64_t k) {
+    if (trans_a || k <= 0 || m < 16384 || n * k > (1L << 22)) return 0;
+    const long tiles_n = (n + BN - 1) / BN, ktiles = (k + BK - 1) / BK;
+    return tiles_n * ktiles * 3 * PLANE * (long)sizeof(__bf16);
+}
+
 extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                             const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
-                            int64_t ldc, const float *bias, void *stream) {
+                            int64_t ldc, const float *bias, void *workspace, int64_t workspace_bytes,
+                            void *stream) {
     LKG_REQUIRE(m >= 0 && n >= 0 && k >= 0, "lkg_gemm_f32: negative size");
     if (m == 0 || n == 0) return LKG_OK;
     LKG_REQUIRE(c && ldc >= n, "lkg_gemm_f32: bad C (ldc=%lld, n=%lld)", (long long)ldc, (long long)n);
@@ -634,8 +642,6 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
             return LKG_ERR_HIP;
         }
     }
-    // Split engine 1: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay
-    // for the extra launch.  The plane workspace is stream-ordered (hipMallocAsync / hipFreeAsync on `s`).
     // LKG_GEMM_F32_ONLY=1 in the environment keeps every product on the f32-input MFMA (the bit-exact k-ordered fmaf
     // chain), e.g. to bisect a numerical difference; read once.
     static const bool f32_only = [] {
@@ -643,25 +649,12 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
         return e && e[0] == '1';
     }();
     const int ktiles = (int)((k + BK - 1) / BK);
-    const long ws_elems = (long)g.tiles_n * ktiles * 3 * PLANE;
+    // Split engine 1: A row-major and B small enough to pre-split per call (a weight matrix), enough rows to pay for
+    // the extra launch -- when the CALLER handed over the workspace for B's planes (lkg_gemm_workspace; no allocation
+    // here).  (below ~16 k rows the call is bound by its host-side issue, ~12 us)
     void *ws = nullptr;
-    // (below ~16 k rows the call is bound by its host-side issue, ~12 us; workspace + pre-split add ~11 us of that)
-    if (!f32_only && !trans_a && k > 0 && m >= 16384 && (long)n * k <= (1L << 22)) {
-        static bool pool_ready = false;     // keep freed workspaces in the pool instead of returning them at every sync
-        if (!pool_ready) {
-            int dev = 0;
-            hipMemPool_t pool;
-            uint64_t keep = UINT64_MAX;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            (void)hipGetLastError();
-            pool_ready = true;
-        }
-        if (hipMallocAsync(&ws, ws_elems * sizeof(__bf16), s) != hipSuccess) {
-            (void)hipGetLastError();
-            ws = nullptr;          // no pool memory: the f32 engine below needs none
-        }
-    }
+    const int64_t need = lkg_gemm_workspace(trans_a, m, n, k);
+    if (!f32_only && need > 0 && workspace && workspace_bytes >= need) ws = workspace;
     if (ws) {
         hipLaunchKernelGGL(presplit_b_kernel, dim3((unsigned)(g.tiles_n * ktiles)), dim3(256), 0, s, b, (long)ldb,
                            (int)(trans_b != 0), (long)n, (long)k, ktiles, reinterpret_cast<__bf16 *>(ws));
@@ -669,12 +662,7 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
         g.ktiles_b = ktiles;
     }
     g.split_km = (!f32_only && trans_a && !trans_b && k >= 2048) ? 1 : 0;   // long reductions over rows: weight gradients
-    const int rc = run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
-    if (ws && hipFreeAsync(ws, s) != hipSuccess) {
-        lkg_set_error("lkg_gemm_f32: hipFreeAsync failed");
-        return LKG_ERR_HIP;
-    }
-    return rc;
+    return run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)splits), s);
 }
 
 extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int64_t max_seg_len,

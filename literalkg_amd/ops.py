@@ -136,8 +136,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if not trans_a and k > 0 and tall_ok(m, n, (k,)):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
+    need = int(N.load().lkg_gemm_workspace(int(trans_a), m, n, k)) if _ENGINE != "f32" else 0
+    ws = _workspace(need, out.device) if need else None
     N.call("lkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, float(alpha), N.ptr(a), _ld(a), N.ptr(b), _ld(b),
-           float(beta), N.ptr(out), _ld(out), N.ptr(bias), _stream())
+           float(beta), N.ptr(out), _ld(out), N.ptr(bias), N.ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return out
 
 
