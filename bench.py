@@ -315,6 +315,39 @@ class Timer:
         return float(el), events
 
 
+class Watchdog:
+    """N > 1 only.  The robust measurements come first; every optional phase after them (the pipelined exchange, which
+    had never run over RCCL on the development boxes; the rows scheme; the integrated step) runs under a deadline.  If a
+    phase hangs -- a collective that never completes cannot be caught as an exception -- rank 0 prints the JSON line of
+    what HAS been measured, naming the phase, and every rank leaves with exit code 0 instead of losing the run."""
+
+    def __init__(self, rank, emit):
+        self.rank, self.emit, self.timer, self.phase = rank, emit, None, None
+
+    def arm(self, seconds, phase):
+        import threading
+        self.disarm()
+        self.phase = phase
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        try:
+            if self.rank == 0:
+                out = self.emit(f"phase '{self.phase}' did not finish within its deadline and was abandoned")
+                if out is not None:
+                    sys.stdout.write(json.dumps(out) + "\n")
+                    sys.stdout.flush()
+        finally:
+            os._exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,7 +491,7 @@ def main():
         grad_block = torch.randn((world, n_loc, dg), device=dev)     # stand-in for the dense part's gradient
         grad_slab = torch.randn((n_glob, dg), device=dev)
         grad_table = torch.empty((n_glob, dg), device=dev)
-        plain = [bool(args.no_overlap)]
+        plain = [True]
 
         def step(ev=None):
             if ev is not None:
@@ -484,12 +517,43 @@ def main():
             if ev is not None:
                 ev[3].record()
 
-        exchange = "all_to_all" if plain[0] else "pipelined"
-        if not plain[0]:
-            # The pipelined exchange (batched point-to-point sends behind the SpMM, async column pieces) had not run
-            # over RCCL before this script's first multi-GPU run.  Only an error of the COLLECTIVE LIBRARY switches to
-            # the plain all-to-all form (and says so in the JSON); anything else (a kernel launch error, a shape bug)
-            # is re-raised.  The ranks agree on the outcome; if that agreement itself fails the run exits non-zero.
+        def measure(exchange):
+            for _ in range(max(args.warmup, 1)):
+                step()
+            got = torch.cat([row_block[:, i - lo, :].reshape(1, -1) for i in probe])
+            ok = torch.allclose(got, want, rtol=1e-4, atol=1e-6)
+            elapsed, events = timer.run(step, args.steps, 4)
+            ok, total = reduce_flags(ok, g.nnz, False)
+            xch = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if plain[0] else None
+            return {"elapsed": elapsed, "total_entries": total, "valid": ok,
+                    "step_bwd_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in events])),
+                    "exchange_ms": xch, "exchange": exchange}
+
+        # (1) the plain form first: one all-to-all after the SpMM, one before the transpose SpMM -- standard collectives
+        res = measure("all_to_all")
+
+        # the same loop without the layout exchange (the SpMM hot path alone, which needs no collective): the
+        # roofline of the dominant KERNEL comes from here (in the pipelined step the forward is cut into row-range
+        # launches interleaved with the sends); not part of the timed region above
+        def bare(ev):
+            ev[0].record()
+            fs.forward(slab, out=side_slab)
+            ev[1].record()
+            fs.backward(grad_slab, out=grad_table)
+            ev[2].record()
+        bare_elapsed, kev = timer.run(bare, args.steps, 3)
+        res.update({"fwd_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in kev])),
+                    "bwd_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in kev])),
+                    "fwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg), "bwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg),
+                    "spmm_only_ms": bare_elapsed / args.steps * 1e3, "dg": dg})
+        results["features"] = res
+
+        # (2) the pipelined exchange (batched point-to-point sends behind the SpMM, async column pieces), under the
+        # watchdog.  Only an error of the COLLECTIVE LIBRARY is tolerated (and reported); a kernel launch error or a
+        # shape bug is re-raised.  The ranks agree on the outcome; if that agreement itself fails the run exits non-zero.
+        if not args.no_overlap:
+            watchdog.arm(300, "features scheme, pipelined exchange")
+            plain[0] = False
             ok, why = 1.0, ""
             try:
                 step()
@@ -500,64 +564,31 @@ def main():
                 ok, why = 0.0, f"{type(exc).__name__}: {exc}"
             flag = torch.tensor([ok], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag) == 0.0:
-                plain[0] = True
-                exchange = f"all_to_all (fallback: {(why or 'failed on another rank')[:200]})"
-        for _ in range(max(args.warmup, 1)):
-            step()
-        got = torch.cat([row_block[:, i - lo, :].reshape(1, -1) for i in probe])
-        ok = torch.allclose(got, want, rtol=1e-4, atol=1e-6)
-        elapsed, events = timer.run(step, args.steps, 4)
-        ok, total = reduce_flags(ok, g.nnz, False)
+            if float(flag) == 1.0:
+                pipe = measure("pipelined")
+                pipe.update({k: res[k] for k in ("fwd_ms", "bwd_ms", "fwd_bytes", "bwd_bytes", "spmm_only_ms", "dg")})
+                results["features_pipelined"] = pipe
+            else:
+                res["pipelined_exchange_error"] = (why or "failed on another rank")[:300]
+            watchdog.disarm()
 
-        # the same loop without the layout exchange (the SpMM hot path alone, which needs no collective): the
-        # roofline of the dominant KERNEL comes from here (in the timed step the forward is cut into row-range
-        # launches interleaved with the sends); not part of the timed region above
-        def bare(ev):
-            ev[0].record()
-            fs.forward(slab, out=side_slab)
-            ev[1].record()
-            fs.backward(grad_slab, out=grad_table)
-            ev[2].record()
-        bare_elapsed, kev = timer.run(bare, args.steps, 3)
-        xch = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if plain[0] else None
-        return {"elapsed": elapsed, "total_entries": total, "valid": ok,
-                "fwd_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in kev])),
-                "bwd_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in kev])),
-                "step_bwd_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in events])),
-                "fwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg), "bwd_bytes": algorithmic_bytes(g.nnz, n_glob, dg),
-                "spmm_only_ms": bare_elapsed / args.steps * 1e3, "exchange_ms": xch, "exchange": exchange, "dg": dg}
-
-    results = {}
-    for scheme in schemes:
-        results[scheme] = run_features() if scheme == "features" else run_rows()
-        torch.cuda.empty_cache()
-
-    sharded_step = None
-    if world > 1 and not args.no_sharded_step:
-        # after the headline measurements; an ordinary error here is reported in the JSON and does not cost the run
-        # (every rank takes the same branch: the agreement below is a collective)
-        ok, why = 1.0, ""
-        try:
-            sharded_step = sharded_step_timings(world, rank, dev, n_glob, d, h, t, r, max(3, min(args.steps, 10)))
-        except LkgError as exc:
-            ok, why = 0.0, f"LkgError: {exc}"
-        except RuntimeError as exc:
-            ok, why = 0.0, f"{type(exc).__name__}: {exc}"
-        flag = torch.tensor([ok], device=cdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag) == 0.0:
-            sharded_step = {"error": (why or "failed on another rank")[:300]}
-
-    if rank == 0:
-        head = schemes[0]
+    # ------------------------------------------------------------------ run + report
+    def assemble(note=None):
+        """The JSON line from whatever has been measured so far (rank 0)."""
+        if not results:
+            return None
+        head = next(k for k in ("none", "features_pipelined", "features", "rows") if k in results)
+        if head == "features_pipelined" and not (results[head]["valid"] and
+                                                 results[head]["elapsed"] <= results["features"]["elapsed"]):
+            head = "features"                          # the pipelined exchange must be correct AND faster to be the headline
         res = results[head]
+        kind = "features" if head.startswith("features") else head
         total = res["total_entries"]
         achieved = res["fwd_bytes"] / (res["fwd_ms"] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(res["fwd_bytes"]) if world == 1 else (None, "N > 1: not collected")
         workload = (f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
                     + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
-                       "features": " + RCCL exchange (column slab <-> row block) both ways"}[head]
+                       "features": " + RCCL exchange (column slab <-> row block) both ways"}[kind]
                     + f"; synthetic KG {n_glob} entities / {total} stored (h,t) entries "
                       f"({e_loc * world} triples, R=16, {args.skew} heads)")
         out = {
@@ -576,7 +607,7 @@ def main():
                 "sharding": {"none": "none",
                              "rows": f"head-row ranges x{world}, replicated table, gradient all-reduce",
                              "features": f"feature columns x{world} (D/G={d // world}), replicated structure, "
-                                         f"column slab <-> row block exchange"}[head],
+                                         f"column slab <-> row block exchange"}[kind],
                 "exchange": res["exchange"],
                 "skew": args.skew,
                 "host_graph_build_s": round(t_build, 2),
@@ -585,16 +616,16 @@ def main():
                 "spmm_only_edges_per_s": (2 * total / res["spmm_only_ms"] * 1e3) if res.get("spmm_only_ms") else None,
             },
             "roofline": {"bound": "hbm",
-                         "kernel": "spmm_csr_kernel (forward launch)" if head != "features" else
+                         "kernel": "spmm_csr_kernel (forward launch)" if kind != "features" else
                                    "spmm_csr_kernel (forward launch over this rank's column slab, timed in the "
-                                   "exchange-free loop; the timed step cuts it into row-range launches between sends)",
+                                   "exchange-free loop)",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "spmm_source_sha16": source_sha(),
                          "algorithmic_bytes_per_launch": res["fwd_bytes"], "avg_launch_ms": res["fwd_ms"],
                          "bwd_launch_ms": res["bwd_ms"],
                          "bwd_achieved_GBs": res["bwd_bytes"] / (res["bwd_ms"] * 1e-3) / 1e9
-                         if (head != "rows") else None,
+                         if (kind != "rows") else None,
                          "step_bwd_ms_including_exchange": res.get("step_bwd_ms"),
                          "exchange_ms": res.get("exchange_ms"),
                          "note": "achieved = algorithmic bytes / HIP-event time of one lkg_spmm_csr_f32 call (one "
@@ -602,7 +633,15 @@ def main():
                                  "because slabs of the source table are partly served from the 256 MiB Infinity Cache, "
                                  "whose hits the fabric-side FETCH_SIZE counter (traffic) still counts"},
         }
-        if "rows" in results and head != "rows":      # the north star's scheme, same graph shape, next to the headline
+        if kind == "features":      # both exchange forms of the headline scheme, whichever is the headline
+            out["features_exchanges"] = {
+                k: {"value": 2 * v["total_entries"] * args.steps / v["elapsed"], "ms_per_step": v["elapsed"] / args.steps * 1e3,
+                    "exchange": v["exchange"], "spot_check": "ok" if v["valid"] else "MISMATCH",
+                    "step_bwd_ms_including_exchange": v.get("step_bwd_ms"), "exchange_ms": v.get("exchange_ms")}
+                for k, v in results.items() if k.startswith("features")}
+            if "pipelined_exchange_error" in results["features"]:
+                out["features_exchanges"]["pipelined_exchange_error"] = results["features"]["pipelined_exchange_error"]
+        if "rows" in results and kind != "rows":      # the north star's scheme, same graph shape, next to the headline
             rr = results["rows"]
             out["rows_scheme"] = {
                 "sharding": f"head-row ranges x{world}, replicated table, gradient all-reduce",
@@ -612,13 +651,46 @@ def main():
                 "fwd_frac_of_hbm_roofline": rr["fwd_bytes"] / (rr["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "exchange": rr["exchange"],
                 "spot_check": "ok" if rr["valid"] else "MISMATCH"}
-        if sharded_step is not None:
-            out["sharded_pre_training_step"] = sharded_step
+        if state["sharded_step"] is not None:
+            out["sharded_pre_training_step"] = state["sharded_step"]
+        if note:
+            out["note"] = note
+        return out
+
+    results, state = {}, {"sharded_step": None}
+    watchdog = Watchdog(rank, assemble)
+    for scheme in schemes:
+        if scheme == "features":
+            run_features()                             # fills results["features"] (+ "features_pipelined")
+        else:
+            if world > 1:
+                watchdog.arm(300, "rows scheme (chunked all-reduce behind the transpose SpMM)")
+            results[scheme] = run_rows()
+            watchdog.disarm()
+        torch.cuda.empty_cache()
+
+    if world > 1 and not args.no_sharded_step:
+        # after the headline measurements; an ordinary error here is reported in the JSON and does not cost the run
+        # (every rank takes the same branch: the agreement below is a collective), a hang is the watchdog's
+        watchdog.arm(420, "integrated sharded pre_training step")
+        ok, why, got = 1.0, "", None
+        try:
+            got = sharded_step_timings(world, rank, dev, n_glob, d, h, t, r, max(3, min(args.steps, 10)))
+        except LkgError as exc:
+            ok, why = 0.0, f"LkgError: {exc}"
+        except RuntimeError as exc:
+            ok, why = 0.0, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([ok], device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        state["sharded_step"] = got if float(flag) == 1.0 else {"error": (why or "failed on another rank")[:300]}
+        watchdog.disarm()
+
+    if rank == 0:
+        out = assemble()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g_own, res["val"], n_glob, d, 2022)
+            out["cpu_baseline"] = cpu_baseline(g_own, results["none"]["val"], n_glob, d, 2022)
         if world == 1 and not args.no_extra:
             results.clear()
-            del res
             torch.cuda.empty_cache()
             out["extra"] = whole_path_timings(h, t, r, n_glob, d, dev)
         print(json.dumps(out))

@@ -123,3 +123,29 @@ def test_two_ranks_over_rccl(gpu_device):
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)], res
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_rank_rehearsal_starts_its_own_workers(gpu_device):
+    """`python bench.py --gpus 2` without a torch.distributed environment starts its two workers itself (here both on
+    the one GPU, over gloo: a rehearsal of the N > 1 code path, not a measurement) and prints ONE JSON line carrying
+    both exchange forms of the feature scheme, the north star's row-range scheme and the integrated sharded step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu",
+                          "--steps", "2", "--warmup", "1", "--entities", "40000", "--edges", "400000"],
+                         capture_output=True, text=True, timeout=580, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and "REHEARSAL" in j["data"]
+    assert j["config"]["spot_check"] == "ok" and j["config"]["exchange"] in ("all_to_all", "pipelined")
+    fx = j["features_exchanges"]
+    assert fx["features"]["spot_check"] == "ok" and fx["features_pipelined"]["spot_check"] == "ok"
+    assert j["rows_scheme"]["spot_check"] == "ok" and j["rows_scheme"]["value"] > 0
+    st = j["sharded_pre_training_step"]
+    assert "error" not in st and st["rows"]["ms_per_step"] > 0 and st["features"]["ms_per_step"] > 0
+    assert "note" not in j                                   # no phase was abandoned by the watchdog
