@@ -135,12 +135,15 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
  *                      (the concatenated table keeps a copy of the layer input, model.py:300-309), which autograd
  *                      would otherwise add in a separate N x D pass;
  *   copy_src/copy_dst  copy_dst[i,:] = copy_src[i,:] -- in the forward, that copy itself (the raw entity table into
- *                      column slot 0 of the concatenated table when no gate is configured).                      */
+ *                      column slot 0 of the concatenated table when no gate is configured);
+ *   rowmax_out         float[n_rows] (cleared here): max |out[i,:]| -- the row scale the tall GEMM of the layer's
+ *                      Linear needs of its input (lkg_gemm_tall_f32), produced while the row is in registers.   */
 int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                            const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                            const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                            const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
-                           const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
+                           float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
+                           void *stream);
 
 /* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
  * layer only needs the rows its consumers read.  lkg_csr_extract_rows copies the entries of the (sorted,
@@ -324,13 +327,14 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
 
 /* Backward of the epilogue.  g_y and g_yn (nullable) are the upstream gradients of
  * the two outputs; writes g_z (n x d) and ACCUMULATES g_gamma / g_beta (atomic,
- * zero-initialised by the caller).                                                 */
+ * zero-initialised by the caller).  g_z_rowmax (nullable, float[n]) receives max |g_z[i,:]|:
+ * the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32), for free.  */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
-                              float drop_p, uint64_t seed, void *stream);
+                              float drop_p, uint64_t seed, float *g_z_rowmax, void *stream);
 
 /* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
  *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)

@@ -23,12 +23,18 @@
 // 16-k steps, 2 x BN/64 waves of 64 x 64, double-buffered LDS planes, one barrier per step: barrier -> split + write
 // tile t+1 -> re-issue the loads of tile t+2 -> 12 MFMAs of tile t.  B arrives as ready-made fp16 planes (prepared once
 // per call in the caller's workspace, an exact image of the LDS tile).
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
 
 #include "lkg_common.h"
 
 namespace {
 
+#ifndef LKG_TALL_DEFAULT_VARIANT
+#define LKG_TALL_DEFAULT_VARIANT 2      /* 256x1: measured fastest (1 M x 256 x 256: 0.62 ms against 0.76 / 0.71) */
+#endif
 constexpr int TM = 128, TK = 16, MAX_PANELS = 3;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -109,16 +115,18 @@ __device__ __forceinline__ float b_elem(const BDesc &b, int group, int row, int 
     return b.trans_b ? src[(long)row * b.ld[group][p] + k] : src[(long)k * b.ld[group][p] + row];
 }
 
-// exponent of every stacked B row (thread per row; B is a few hundred KB)
-__global__ void b_exponent_kernel(BDesc b, int n_stacked, int *__restrict__ eb) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+// exponent of every stacked B row: one wave per row, lanes stride over k
+__global__ __launch_bounds__(256) void b_exponent_kernel(BDesc b, int n_stacked, int *__restrict__ eb) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_stacked) return;
     int group, row;
     float mx = 0.f;
     if (b_source(b, s, group, row))
         for (int p = 0; p < b.n_panels; ++p)
-            for (int k = 0; k < b.k[p]; ++k) mx = fmaxf(mx, fabsf(b_elem(b, group, row, p, k)));
-    eb[s] = scale_exponent(mx);
+            for (int k = lane; k < b.k[p]; k += 64) mx = fmaxf(mx, fabsf(b_elem(b, group, row, p, k)));
+    mx = wave_max(mx);
+    if (lane == 0) eb[s] = scale_exponent(mx);
 }
 
 // planes of one (n tile, k tile): thread = tile row
@@ -151,8 +159,13 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
 }
 
 // ---------------------------------------------------------------------------------------------- the GEMM
-template <int BN, int EPI>
-__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tall_kernel(TallArgs g) {
+// ONE: a single accumulator per tile.  The 2^-11 of the two cross terms is then applied to an OPERAND instead of to a
+// second accumulator: hs = hi * 2^-11 (an exact exponent shift, one v_pk_mul_f16 per register, down to fp16's
+// subnormals for elements below 2^-17 of their row maximum) and  a'.b' = hi_a hi_b + hs_a mid_b + mid_a hs_b.  64
+// accumulator registers less per lane: three 4-wave workgroups (or two 8-wave ones) share a CU and their phases overlap.
+template <int BN, int EPI, bool ONE>
+__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(ONE ? (BN == 128 ? 3 : 4) : 2, ONE ? (BN == 128 ? 3 : 4) : 2)))
+void gemm_tall_kernel(TallArgs g) {
     constexpr int NT = 2 * BN;                    // threads
     constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
     constexpr int TPR = TK / EPT;                 // threads per A row
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // needs -- x is the gate's first K-panel, so the columns of this tile pass through the staging registers anyway
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     int *ea_s = reinterpret_cast<int *>(smem + 2 * BUF);
-    constexpr int XP = 132;                        // stash pitch (floats): 128 columns + 4, conflict-free 16-byte writes
+    constexpr int XP = BN / 2 + 4;                 // stash pitch (floats): the tile's output columns + 4, conflict-free 16-byte writes
     float *xstash = reinterpret_cast<float *>(smem + 2 * BUF + 2 * TM);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -184,13 +197,16 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const long grow = min(m0 + arow, g.m - 1);               // clamped: rows past m are computed and never stored
     const int ea = scale_exponent(g.a_rowmax[grow]);
 
-    f32x16 acc[2][2], cor[2][2];
+    f32x16 acc[2][2], cor[ONE ? 1 : 2][ONE ? 1 : 2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = cor[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (!ONE) cor[i][j][r] = 0.f;
+            }
 
     // ONE branch-free load path for every tile of every panel (aligned or not, full or partial): a 16-byte window per
     // thread, its address clamped to the panel's last valid window (rows past m reuse row m-1, never stored; a window
@@ -266,9 +282,13 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             av[4 * q + 3] = kk + 3 < raw_kp ? e3 : 0.f;
         }
         if constexpr (EPI == EPI_GATE) {          // keep x[rows of the tile, output columns of the tile] for the epilogue
-            const int c = raw_k0 - (n0 >> 1);     // (EPT = 4 at BN = 256)
-            if (raw_first && c >= 0 && c < 128)
-                *reinterpret_cast<float4 *>(xstash + arow * XP + c) = make_float4(av[0], av[1], av[2], av[3]);
+#pragma unroll
+            for (int q = 0; q < EPT / 4; ++q) {
+                const int c = raw_k0 + 4 * q - (n0 >> 1);
+                if (raw_first && c >= 0 && c < BN / 2)
+                    *reinterpret_cast<float4 *>(xstash + arow * XP + c) =
+                        make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
+            }
         }
         _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
 #pragma unroll
@@ -298,14 +318,32 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        if constexpr (ONE) {
+            const _Float16 sc = (_Float16)(1.f / 2048.f);
+            f16x8 ahs[2], bhs[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                ahs[i] = a[i][0] * sc;
+                bhs[i] = b[i][0] * sc;
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], cor[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs[i], b[j][1], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], cor[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bhs[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], cor[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], cor[i][j], 0, 0, 0);
+        }
     };
 
     // One register set, one barrier per step, no branch in the loop (the accumulators never meet a control-flow join):
@@ -376,7 +414,8 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
-                    const float v = fmaf(cor[i][j][r], 1.f / 2048.f, acc[i][j][r]);
+                    float v = acc[i][j][r];
+                    if constexpr (!ONE) v = fmaf(cor[i][j][r], 1.f / 2048.f, v);
                     out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
                 }
                 put(out);
@@ -403,8 +442,13 @@ __global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     const int e = ea_s[lr0 + dr];
-                    const float gp = ldexpf(fmaf(cor[i][0][r], 1.f / 2048.f, acc[i][0][r]), -(e + ebg)) + bg;
-                    const float zp = ldexpf(fmaf(cor[i][1][r], 1.f / 2048.f, acc[i][1][r]), -(e + ebz)) + bz;
+                    float gs = acc[i][0][r], zs = acc[i][1][r];
+                    if constexpr (!ONE) {
+                        gs = fmaf(cor[i][0][r], 1.f / 2048.f, gs);
+                        zs = fmaf(cor[i][1][r], 1.f / 2048.f, zs);
+                    }
+                    const float gp = ldexpf(gs, -(e + ebg)) + bg;
+                    const float zp = ldexpf(zs, -(e + ebz)) + bz;
                     gv[r] = tanh_fast(gp);
                     zv[r] = sigmoid_fast(zp);
                     ov[r] = fmaf(zv[r], gv[r] - xv[r], xv[r]);        // (1 - z) x + z g
@@ -453,12 +497,24 @@ inline int total_ktiles(int n_panels, const int32_t *ka) {
 }
 // tile width and number of column tiles: the gate's stacked columns are interleaved in blocks of 32 (g, z, g, z ...), so
 // its stacked extent is 64 per 32 output columns
+// variant: LKG_TALL_VARIANT = "256x2" (two accumulators, 128 x 256 tiles), "128x1" / "256x1" (one accumulator)
+inline int tall_variant() {
+    static const int v = [] {
+        const char *e = getenv("LKG_TALL_VARIANT");
+        if (e && !strcmp(e, "256x2")) return 0;
+        if (e && !strcmp(e, "256x1")) return 2;
+        if (e && !strcmp(e, "128x1")) return 1;
+        return LKG_TALL_DEFAULT_VARIANT;
+    }();
+    return v;
+}
 inline void geometry(int n, int epilogue, int &bn, int &tiles_n) {
+    const int v = tall_variant();
     if (epilogue == EPI_GATE) {
-        bn = 256;
+        bn = v == 1 ? 128 : 256;
         tiles_n = ((n / 2 + 31) / 32 * 64 + bn - 1) / bn;
     } else {
-        bn = n <= 128 ? 128 : 256;
+        bn = (n <= 128 || v == 1) ? 128 : 256;
         tiles_n = (n + bn - 1) / bn;
     }
 }
@@ -532,7 +588,7 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     int *eb = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) +
                                       (long)g.tiles_n * g.ktiles_total * (2L * bn * TK) * 2);
     const int n_stacked = g.tiles_n * bn;
-    hipLaunchKernelGGL(b_exponent_kernel, dim3((n_stacked + 127) / 128), dim3(128), 0, s, bd, n_stacked, eb);
+    hipLaunchKernelGGL(b_exponent_kernel, dim3((n_stacked + 3) / 4), dim3(256), 0, s, bd, n_stacked, eb);
     if (bn == 256)
         hipLaunchKernelGGL((b_planes_kernel<256>), dim3(g.tiles_n * g.ktiles_total), dim3(256), 0, s, bd, g.ktiles_total, eb, planes);
     else
@@ -541,23 +597,35 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     auto lds_bytes = [](int bn_, bool gate) {
-        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + TM * 4 + (gate ? TM * 132 * 4 : 0);
+        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + TM * 4 + (gate ? TM * (bn_ / 2 + 4) * 4 : 0);
     };
-    static bool lds_raised = false;
-    if (!lds_raised) {       // the gate variant needs 117 KB of dynamic LDS (default limit 64 KB)
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<256, EPI_GATE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256, true)) != hipSuccess) {
-            lkg_set_error("lkg_gemm_tall_f32: cannot raise the dynamic LDS limit");
-            return LKG_ERR_HIP;
-        }
-        lds_raised = true;
+    const int lds = lds_bytes(bn, epilogue == EPI_GATE);
+    const bool one = tall_variant() != 0;
+#define LKG_TALL_GO(BN_, EPI_, ONE_)                                                                                   \
+    do {                                                                                                               \
+        static bool raised = false;                                                                                    \
+        if (!raised && lds > 48 * 1024) {                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {                  \
+                lkg_set_error("lkg_gemm_tall_f32: cannot raise the dynamic LDS limit");                                \
+                return LKG_ERR_HIP;                                                                                    \
+            }                                                                                                          \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_>), grid, dim3(2 * BN_), lds, s, g);                       \
+    } while (0)
+    if (epilogue == EPI_GATE) {
+        if (bn == 256 && !one) LKG_TALL_GO(256, EPI_GATE, false);
+        else if (bn == 256) LKG_TALL_GO(256, EPI_GATE, true);
+        else LKG_TALL_GO(128, EPI_GATE, true);
+    } else if (bn == 256) {
+        if (!one) LKG_TALL_GO(256, EPI_PLAIN, false);
+        else LKG_TALL_GO(256, EPI_PLAIN, true);
+    } else {
+        if (!one) LKG_TALL_GO(128, EPI_PLAIN, false);
+        else LKG_TALL_GO(128, EPI_PLAIN, true);
     }
-    if (epilogue == EPI_GATE)
-        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_GATE>), grid, dim3(512), lds_bytes(256, true), s, g);
-    else if (bn == 256)
-        hipLaunchKernelGGL((gemm_tall_kernel<256, EPI_PLAIN>), grid, dim3(512), lds_bytes(256, false), s, g);
-    else
-        hipLaunchKernelGGL((gemm_tall_kernel<128, EPI_PLAIN>), grid, dim3(256), lds_bytes(128, false), s, g);
+#undef LKG_TALL_GO
     LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
     return LKG_OK;
 }

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           const float *__restrict__ g_yn, long ldgyn, float norm_eps,
                                                           float *__restrict__ g_z, long ldgz,
                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta,
-                                                          float drop_p, unsigned long long seed) {
+                                                          float drop_p, unsigned long long seed,
+                                                          float *__restrict__ gz_rowmax) {
     constexpr int K = CPL * W;
     __shared__ float red_g[3][K][64], red_b[3][K][64];
     const int lane = threadIdx.x & 63;
@@ -211,6 +212,13 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
             zz.v[k] = da * (zz.v[k] > 0.f ? 1.f : slope);
         }
         zz.store(g_z + row * ldgz, d, lane);
+        if (gz_rowmax) {      // max |g_z[row, :]|: the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32)
+            float mx = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, zz.live(k, d, lane) ? fabsf(zz.v[k]) : 0.f);
+            mx = wave_max(mx);
+            if (lane == 0) gz_rowmax[row] = mx;
+        }
     }
     // the four waves of the workgroup meet in LDS first: one atomic per workgroup per column (every workgroup
     // hits the same 2*d addresses, and contended float atomics are an order of magnitude slower)
@@ -374,7 +382,7 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          const float *gamma, const float *y, int64_t ldy, const float *save_mean,
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
-                                         float *g_beta, float drop_p, uint64_t seed, void *stream) {
+                                         float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax, void *stream) {
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
@@ -389,7 +397,7 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
     const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 1024));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
-                     (unsigned long long)seed);
+                     (unsigned long long)seed, g_z_rowmax);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
     return LKG_OK;
 }

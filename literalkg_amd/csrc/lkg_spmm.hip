@@ -24,6 +24,9 @@ struct vec_ops<float4> {
     static constexpr int W = 4;
     static __device__ __forceinline__ float4 zero() { return f4_zero(); }
     static __device__ __forceinline__ void fma(float4 &a, float s, const float4 &x) { f4_fma(a, s, x); }
+    static __device__ __forceinline__ float absmax(const float4 &a) {
+        return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
     template <int M>
     static __device__ __forceinline__ void xor_add(float4 &a) {
         a.x = lane_xor_add<M>(a.x);
@@ -37,6 +40,7 @@ struct vec_ops<float> {
     static constexpr int W = 1;
     static __device__ __forceinline__ float zero() { return 0.f; }
     static __device__ __forceinline__ void fma(float &a, float s, const float &x) { a = fmaf(s, x, a); }
+    static __device__ __forceinline__ float absmax(const float &a) { return fabsf(a); }
     template <int M>
     static __device__ __forceinline__ void xor_add(float &a) { a = lane_xor_add<M>(a); }
 };
@@ -115,6 +119,7 @@ struct SpmmExtra {
     long ld_copy_src;
     float *copy_dst;
     long ld_copy_dst;
+    int *rowmax;             // rowmax[i] = max |out[i,:]| as the int bits of a non-negative float (atomicMax over the slabs)
     __device__ __forceinline__ void shift(long cols) {
         if (add2) add2 += cols;
         if (copy_dst) {
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                 for (int k = 1; k < 4; ++k) ops::fma(acc[i], 1.f, part[k][i][lane]);
             }
     }
+    float rmax = 0.f;
     if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
         const V *own = self ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
@@ -201,8 +207,13 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                 if (own2) ops::fma(acc[i], 1.f, own2[chunk]);
                 dst[chunk] = acc[i];
                 if (cdst) cdst[chunk] = csrc[chunk];
+                rmax = fmaxf(rmax, ops::absmax(acc[i]));
             }
         }
+    }
+    if (ex.rowmax) {       // (workgroup-uniform; every lane of the wave is here)
+        rmax = wave_max(rmax);
+        if (lane == 0) atomicMax(ex.rowmax + row, __float_as_int(rmax));
     }
 }
 
@@ -250,6 +261,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
         if (self) ops::fma(a, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[lane]);
         if (ex.add2) ops::fma(a, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[lane]);
         reinterpret_cast<V *>(out + (long)row * ldo)[lane] = a;
+        if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(a)));
         if (ex.copy_dst)
             reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst)[lane] =
                 reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src)[lane];
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
         if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[sl]);
         if (ex.add2) ops::fma(acc, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[sl]);
         reinterpret_cast<V *>(out + (long)row * ldo)[sl] = acc;
+        if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(acc)));
         if (ex.copy_dst)
             reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst)[sl] =
                 reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src)[sl];
@@ -370,7 +383,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                                       const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                                       const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                                       const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
-                                      const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
+                                      float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
+                                      void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -389,8 +403,12 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                      (!add2 || (ld_add2 % 4 == 0 && lkg_aligned16(add2))) &&
                      (!copy_dst || (ld_copy_src % 4 == 0 && ld_copy_dst % 4 == 0 && lkg_aligned16(copy_src) &&
                                     lkg_aligned16(copy_dst)));
+    if (rowmax_out && hipMemsetAsync(rowmax_out, 0, sizeof(float) * n_rows, s) != hipSuccess) {
+        lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
     const SpmmExtra ex{add2, (long)ld_add2, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
-                       (long)ld_copy_dst};
+                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out)};
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
     // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
@@ -406,7 +424,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
         const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, copy_dst ? copy_src + c0 : nullptr,
-                            (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst};
+                            (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst,
+                            reinterpret_cast<int *>(rowmax_out)};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
                                         self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
@@ -421,7 +440,7 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                 const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                                 int32_t long_thresh, void *stream) {
     return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr, 0,
-                                  nullptr, 0, long_rows, n_long, long_thresh, stream);
+                                  nullptr, 0, nullptr, long_rows, n_long, long_thresh, stream);
 }
 
 // dst[i] = src[perm[i]]

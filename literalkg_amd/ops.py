@@ -97,7 +97,8 @@ def check_deferred_errors():
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
              add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
-             copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+             copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             rowmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
@@ -118,7 +119,8 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
            x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
            _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
            N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
-           N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
+           N.ptr(rowmax), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
+           _stream())
     return out
 
 
@@ -134,7 +136,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         if beta != 0.0:
             raise ValueError("gemm: beta != 0 needs out")
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    if not trans_a and k > 0 and tall_ok(m, n, (k,)):
+    if not trans_a and k > 0 and tall_ok(m, n, (k,), single_panel_too=tagged_rowmax(a) is not None):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
     need = int(N.load().lkg_gemm_workspace(int(trans_a), m, n, k)) if _ENGINE != "f32" else 0
     ws = _workspace(need, out.device) if need else None
@@ -170,6 +172,25 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return w
 
 
+def _wants_rowmax(n_rows: int) -> bool:
+    """Should a producer of an n_rows x d tensor also emit its row maxima (the consumer is likely a tall GEMM)?"""
+    return _ENGINE in ("f16x2", "f16x2-all") and n_rows >= TALL_MIN_ROWS
+
+
+def tag_rowmax(t: torch.Tensor, rm: Optional[torch.Tensor]) -> torch.Tensor:
+    """Remember max |t[i,:]| on the tensor OBJECT (it dies with it; an in-place change of t invalidates it)."""
+    if rm is not None:
+        t._lkg_rowmax = (t._version, rm)
+    return t
+
+
+def tagged_rowmax(t: torch.Tensor) -> Optional[torch.Tensor]:
+    tag = getattr(t, "_lkg_rowmax", None)
+    if tag is None or tag[0] != t._version or tag[1].shape[0] != t.shape[0] or tag[1].device != t.device:
+        return None
+    return tag[1]
+
+
 def row_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """out[i] = max_j |x[i, j]| (accumulate: max with what out holds): the row scale of the tall GEMM's A operand."""
     _need_gpu(x)
@@ -182,9 +203,16 @@ def row_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: 
 
 
 def rows_absmax(panels: Sequence[torch.Tensor]) -> torch.Tensor:
+    """max over the panels of their row maxima; a panel whose producer tagged it costs no pass."""
     out = None
     for p in panels:
-        out = row_absmax(p, out, accumulate=out is not None)
+        rm = tagged_rowmax(p)
+        if rm is not None and out is None and len(panels) == 1:
+            return rm
+        if rm is not None:
+            out = rm.clone() if out is None else torch.maximum(out, rm, out=out)
+        else:
+            out = row_absmax(p, out, accumulate=out is not None)
     return out
 
 
@@ -206,6 +234,8 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
     """C = sum_p a_panels[p] @ op(B_p) (+ bias) for a tall A (lkg_gemm_tall_f32).  b_blocks[g][p]: block of B for row
     group g (1 group; 2 = the gate's stacked g / z projections with the blend epilogue on gate_x) and panel p; trans_b:
     blocks stored [n, k_p] (nn.Linear weights) else [k_p, n].  keep = (g_out, z_out) for the gate's backward."""
+    if rowmax is None:
+        rowmax = rows_absmax(a_panels)          # (before any .contiguous(): the producers' tags live on these objects)
     a_panels = [_f32_rows(a) for a in a_panels]
     m = a_panels[0].shape[0]
     ks = [a.shape[1] for a in a_panels]
@@ -222,8 +252,6 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
             if tuple(b.shape) != ((rows, k) if trans_b else (k, rows)):
                 raise ValueError(f"gemm_tall: B block of shape {tuple(b.shape)} does not match (rows {rows}, k {k})")
     n = rows * n_groups
-    if rowmax is None:
-        rowmax = rows_absmax(a_panels)
     if out is None:
         if beta != 0.0:
             raise ValueError("gemm_tall: beta != 0 needs out")
@@ -302,8 +330,9 @@ class _Aggregate(Function):
         ctx.g = g
         ctx.val_t = val_t
         ctx.plus_self = plus_self
-        return spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
-                        add_self=ego if plus_self else None)
+        rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
+        return tag_rowmax(spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
+                                   add_self=ego if plus_self else None, rowmax=rm), rm)
 
     @staticmethod
     def backward(ctx, grad):
@@ -337,9 +366,10 @@ class _AggregateKeep(Function):
         kept = ego
         if keep_dst is not None and (keep_dst.data_ptr() != ego.data_ptr() or keep_dst.stride() != ego.stride()):
             copy, kept = (ego, keep_dst), keep_dst
+        rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
         side = spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
-                        add_self=ego if plus_self else None, copy=copy)
-        return side, kept          # kept may be the input itself: autograd aliases it as this node's output
+                        add_self=ego if plus_self else None, copy=copy, rowmax=rm)
+        return tag_rowmax(side, rm), kept          # kept may be the input itself: autograd aliases it as this node's output
 
     @staticmethod
     def backward(ctx, g_side, g_kept):
@@ -367,7 +397,8 @@ class _MultiLinear(Function):
         xs, ws = xw[:n_terms], xw[n_terms:]
         _need_gpu(*xs, *ws)
         y = None
-        if tall_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs]):
+        if tall_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs],
+                   single_panel_too=tagged_rowmax(xs[0]) is not None):
             # every panel in ONE launch: the accumulators stay in registers, the inputs are read once
             y = gemm_tall(xs, (ws,), True, bias)
         else:
@@ -390,8 +421,8 @@ class _MultiLinear(Function):
         for i in range(n):
             if not ctx.needs_input_grad[2 + i]:
                 gxs.append(None)
-            elif tall_ok(gy.shape[0], ws[i].shape[1], (gy.shape[1],)):
-                rm = row_absmax(gy) if rm is None else rm       # one scale pass serves every data gradient
+            elif tall_ok(gy.shape[0], ws[i].shape[1], (gy.shape[1],), single_panel_too=tagged_rowmax(gy) is not None):
+                rm = rows_absmax((gy,)) if rm is None else rm    # one scale (tagged by the producer, or one pass) for all
                 gxs.append(gemm_tall((gy,), ((ws[i],),), False, rowmax=rm))
             else:
                 gxs.append(gemm(gy, ws[i]))
@@ -544,11 +575,12 @@ class _ActLayerNorm(Function):
         gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
         gg = torch.zeros(d, dtype=torch.float32, device=z.device)
         gb = torch.zeros(d, dtype=torch.float32, device=z.device)
+        rm = torch.empty(n, dtype=torch.float32, device=z.device) if _wants_rowmax(n) else None    # for the Linear's data gradient
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               float(drop_p), int(seed), _stream())
-        return (gz, gg, gb) + none[3:]
+               float(drop_p), int(seed), N.ptr(rm), _stream())
+        return (tag_rowmax(gz, rm), gg, gb) + none[3:]
 
 
 def new_seed() -> int:

@@ -23,6 +23,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfgs = {
     "c2": dict(embed_dim=128, relation_dim=128, conv_dim=128, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
+    "d256": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "c3": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=2, use_num_lit=True, use_txt_lit=True),
     # BASELINE config[4] shape on one GPU (scale the graph with --n/--e): D=512, 3 layers, TransR, K=256 negatives
     "c5": dict(embed_dim=512, relation_dim=512, conv_dim=512, n_conv_layers=3, use_num_lit=False, use_txt_lit=False,
