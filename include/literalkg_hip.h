@@ -134,6 +134,8 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
  *   add2               out[i,:] += add2[i,:]  -- in the backward, the gradient that reaches `ego` through its OTHER use
  *                      (the concatenated table keeps a copy of the layer input, model.py:300-309), which autograd
  *                      would otherwise add in a separate N x D pass;
+ *   add2_rows          (nullable, uint8[n_rows]) add2 is read for the rows whose byte is non-zero only: the loss's
+ *                      gradient of the concatenated table touches <= 3B rows (lkg_fill_rows_f32 keeps the flags);
  *   copy_src/copy_dst  copy_dst[i,:] = copy_src[i,:] -- in the forward, that copy itself (the raw entity table into
  *                      column slot 0 of the concatenated table when no gate is configured);
  *   rowmax_out         float[n_rows] (cleared here): max |out[i,:]| -- the row scale the tall GEMM of the layer's
@@ -141,8 +143,8 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
 int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                            const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                            const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
-                           const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
-                           float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
+                           const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src, float *copy_dst,
+                           int64_t ld_copy_dst, float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
                            void *stream);
 
 /* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
@@ -227,6 +229,11 @@ int lkg_gather_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, con
 /* dst[idx[perm[i]],:] += src[i,:]  (f32 atomics; autograd of the row gathers model.py:382-384)     */
 int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds, const int64_t *idx,
                              const int32_t *perm, float *dst, int64_t ldd, void *stream);
+/* dst[idx[i],:] = value (dst nullable) and flags[idx[i]] = (flag != 0) (flags nullable, uint8 per table row): marks or
+ * resets the <= 3B rows a loss gradient touches in an N-row table that is otherwise kept all-zero between steps, so that
+ * no N x C fill runs per step (ops._RowScratch).                                                   */
+int lkg_fill_rows_f32(int64_t n, int32_t d, const int64_t *idx, float *dst, int64_t ldd, float value, uint8_t *flags,
+                      int32_t flag, void *stream);
 /* Row-range forms for a table sharded by rows over the ranks of one node (literalkg_amd/distributed.py): this rank
  * holds rows [row_lo, row_hi) and src / dst point at row row_lo.
  *   gather : dst[i,:] = src[idx[i] - row_lo,:] when idx[i] is in the range, else 0 (the rows owned by other ranks are
@@ -328,13 +335,17 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
 /* Backward of the epilogue.  g_y and g_yn (nullable) are the upstream gradients of
  * the two outputs; writes g_z (n x d) and ACCUMULATES g_gamma / g_beta (atomic,
  * zero-initialised by the caller).  g_z_rowmax (nullable, float[n]) receives max |g_z[i,:]|:
- * the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32), for free.  */
+ * the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32), for free.
+ * g_yn_rows (nullable, uint8[n]): g_yn is known to be zero outside the rows whose byte is non-zero (the loss's
+ * row-sparse gradient, lkg_fill_rows_f32) -- those rows skip the g_yn / y reads, and with g_y == NULL the whole
+ * row (g_z = 0, no z read either).                                                              */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
-                              float drop_p, uint64_t seed, float *g_z_rowmax, void *stream);
+                              float drop_p, uint64_t seed, float *g_z_rowmax, const uint8_t *g_yn_rows,
+                              void *stream);
 
 /* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
  *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)

@@ -96,6 +96,20 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(long n, int d, co
     for (int c = lane; c < d; c += 64) atomicAdd(dst + r * ldd + c, src[i * lds + c]);
 }
 
+// dst[idx[i], :] = value and, when given, flags[idx[i]] = flag: resets (or marks) the few rows a row-sparse gradient touched
+// in a table that is otherwise kept all-zero between steps (duplicates in idx write the same bytes)
+__global__ __launch_bounds__(256) void fill_rows_kernel(long n, int d, const long *__restrict__ idx, float *__restrict__ dst,
+                                                         long ldd, float value, unsigned char *__restrict__ flags,
+                                                         unsigned char flag) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const long r = idx[i];
+    if (dst)
+        for (int c = lane; c < d; c += 64) dst[r * ldd + c] = value;
+    if (flags && lane == 0) flags[r] = flag;
+}
+
 // Row-range forms for a table sharded by rows over ranks: this rank holds rows [lo, hi) (src / dst point at row lo).
 //   gather : dst[i,:] = idx[i] in [lo, hi) ? src[idx[i] - lo, :] : 0     (the rows of other ranks arrive by all-reduce)
 //   scatter: dst[idx[i] - lo, :] += src[i,:] for idx[i] in [lo, hi)      (f32 atomics)
@@ -215,6 +229,17 @@ extern "C" int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, 
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (long)n, d, src, (long)lds, (const long *)idx, perm, dst, (long)ldd);
     LKG_CHECK_LAUNCH("lkg_scatter_add_rows_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_fill_rows_f32(int64_t n, int32_t d, const int64_t *idx, float *dst, int64_t ldd, float value,
+                                 uint8_t *flags, int32_t flag, void *stream) {
+    LKG_REQUIRE(n >= 0 && d >= 0 && (!dst || (d > 0 && ldd >= d)), "lkg_fill_rows_f32: bad sizes");
+    if (n == 0 || (!dst && !flags)) return LKG_OK;
+    LKG_REQUIRE(idx, "lkg_fill_rows_f32: null row list");
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)n, d,
+                       (const long *)idx, dst, (long)ldd, value, flags, (unsigned char)(flag != 0));
+    LKG_CHECK_LAUNCH("lkg_fill_rows_f32");
     return LKG_OK;
 }
 

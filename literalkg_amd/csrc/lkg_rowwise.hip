@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           float *__restrict__ g_z, long ldgz,
                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta,
                                                           float drop_p, unsigned long long seed,
-                                                          float *__restrict__ gz_rowmax) {
+                                                          float *__restrict__ gz_rowmax,
+                                                          const unsigned char *__restrict__ gyn_rows) {
     constexpr int K = CPL * W;
     __shared__ float red_g[3][K][64], red_b[3][K][64];
     const int lane = threadIdx.x & 63;
@@ -151,12 +152,19 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
 
     for (long row = wave; row < n; row += nwaves) {
         RowRegs<W, CPL> zz, G, yy;
+        const bool has_gyn = g_yn && (!gyn_rows || gyn_rows[row]);   // wave-uniform
+        if (!g_y && !has_gyn) {   // no gradient reaches this row: g_z = 0, nothing to read or to add to g_gamma / g_beta
+            zz.load(z, 0, lane);   // zeros
+            zz.store(g_z + row * ldgz, d, lane);
+            if (gz_rowmax && lane == 0) gz_rowmax[row] = 0.f;
+            continue;
+        }
         zz.load(z + row * ldz, d, lane);
         if (g_y)
             G.load(g_y + row * ldgy, d, lane);
         else
             G.load(z, 0, lane);   // zeros
-        if (g_yn) {
+        if (has_gyn) {
             RowRegs<W, CPL> gn;
             yy.load(y + row * ldy, d, lane);
             gn.load(g_yn + row * ldgyn, d, lane);
@@ -382,7 +390,8 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          const float *gamma, const float *y, int64_t ldy, const float *save_mean,
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
-                                         float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax, void *stream) {
+                                         float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax,
+                                         const uint8_t *g_yn_rows, void *stream) {
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
@@ -397,7 +406,7 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
     const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 1024));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
-                     (unsigned long long)seed, g_z_rowmax);
+                     (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
     return LKG_OK;
 }

@@ -115,11 +115,15 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
 struct SpmmExtra {
     const float *add2;       // out[i,:] += add2[i,:]
     long ld_add2;
+    const unsigned char *add2_rows;   // nullable: add2 is zero (and not read) outside the rows flagged here
     const float *copy_src;   // copy_dst[i,:] = copy_src[i,:]
     long ld_copy_src;
     float *copy_dst;
     long ld_copy_dst;
     int *rowmax;             // rowmax[i] = max |out[i,:]| as the int bits of a non-negative float (atomicMax over the slabs)
+    __device__ __forceinline__ const float *add2_row(long row) const {
+        return add2 && (!add2_rows || add2_rows[row]) ? add2 + row * ld_add2 : nullptr;
+    }
     __device__ __forceinline__ void shift(long cols) {
         if (add2) add2 += cols;
         if (copy_dst) {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
         const V *own = self ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
-        const V *own2 = ex.add2 ? reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2) : nullptr;
+        const V *own2 = reinterpret_cast<const V *>(ex.add2_row(row));
         const V *csrc = ex.copy_dst ? reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src) : nullptr;
         V *cdst = ex.copy_dst ? reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst) : nullptr;
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
 #pragma unroll
         for (int k = 1; k < 4; ++k) ops::fma(a, 1.f, part[k][lane]);
         if (self) ops::fma(a, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[lane]);
-        if (ex.add2) ops::fma(a, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[lane]);
+        if (const float *a2 = ex.add2_row(row)) ops::fma(a, 1.f, reinterpret_cast<const V *>(a2)[lane]);
         reinterpret_cast<V *>(out + (long)row * ldo)[lane] = a;
         if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(a)));
         if (ex.copy_dst)
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
     if (mine && (FULL || sl < nchunk)) {
         if (len == 0) acc = ops::zero();   // an empty row is exactly 0 (0 * Inf/NaN of the spare gathers must not leak)
         if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[sl]);
-        if (ex.add2) ops::fma(acc, 1.f, reinterpret_cast<const V *>(ex.add2 + (long)row * ex.ld_add2)[sl]);
+        if (const float *a2 = ex.add2_row(row)) ops::fma(acc, 1.f, reinterpret_cast<const V *>(a2)[sl]);
         reinterpret_cast<V *>(out + (long)row * ldo)[sl] = acc;
         if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(acc)));
         if (ex.copy_dst)
@@ -382,9 +386,9 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
 extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                                       const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                                       const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
-                                      const float *copy_src, int64_t ld_copy_src, float *copy_dst, int64_t ld_copy_dst,
-                                      float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
-                                      void *stream) {
+                                      const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src,
+                                      float *copy_dst, int64_t ld_copy_dst, float *rowmax_out, const int32_t *long_rows,
+                                      int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -407,7 +411,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
         return LKG_ERR_HIP;
     }
-    const SpmmExtra ex{add2, (long)ld_add2, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
+    const SpmmExtra ex{add2, (long)ld_add2, add2 ? add2_rows : nullptr, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
                        (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out)};
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
@@ -423,7 +427,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                                      n_long, long_thresh, d / block_cols, block_cols, ex, s);
     for (int c0 = 0; c0 < d; c0 += block_cols) {
         const int dc = min(block_cols, d - c0);
-        const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, copy_dst ? copy_src + c0 : nullptr,
+        const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr,
+                            copy_dst ? copy_src + c0 : nullptr,
                             (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst,
                             reinterpret_cast<int *>(rowmax_out)};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
@@ -439,8 +444,8 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                 const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                                 const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                                 int32_t long_thresh, void *stream) {
-    return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr, 0,
-                                  nullptr, 0, nullptr, long_rows, n_long, long_thresh, stream);
+    return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr,
+                                  nullptr, 0, nullptr, 0, nullptr, long_rows, n_long, long_thresh, stream);
 }
 
 // dst[i] = src[perm[i]]

@@ -368,11 +368,19 @@ class LiteralKG(nn.Module):
                 group = k
         self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         keep = self.last_scores if not self.training else None
+        sparse = self._table_grad_stays_inside()
         if self.scoring == "transr":
             return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
-                                   self.kg_l2loss_lambda, keep, group)
+                                   self.kg_l2loss_lambda, keep, group, sparse)
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
-                               self.kg_l2loss_lambda, keep)
+                               self.kg_l2loss_lambda, keep, sparse)
+
+    def _table_grad_stays_inside(self) -> bool:
+        """Is ``self.gat_embed`` the full N-row table of gat_embeddings()?  Its gradient (<= 3B non-zero rows) is then
+        consumed during the backward pass by this package's Functions only -- column slices of the concatenated table
+        (>= 2 slots, so no slice can become a parameter's .grad as it is) or linear_gat's backward -- and the loss may
+        hand back the shared all-zero table of ops._RowScratch instead of filling N x C zeros per step."""
+        return self.gat_rows is None and len(self.conv_dim_list) >= 2
 
     # ------------------------------------------------------------------ a4/a5 attention refresh
     def _structure_for(self, h_list, t_list, r_list, relations) -> KGStructure:
@@ -463,4 +471,5 @@ class LiteralKG(nn.Module):
         """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
         self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
             head_ids, tail_pos_ids, tail_neg_ids)
-        return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda)
+        return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda,
+                            self._table_grad_stays_inside())

@@ -98,11 +98,12 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
              add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
              copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-             rowmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+             rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
-    epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own)."""
+    epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own).  add2_rows
+    (uint8 per row): add2 is zero outside the flagged rows and is read there only."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -118,7 +119,7 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
     N.call("lkg_spmm_csr_fused_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
            x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
            _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
-           N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
+           N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
            N.ptr(rowmax), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
            _stream())
     return out
@@ -189,6 +190,73 @@ def tagged_rowmax(t: torch.Tensor) -> Optional[torch.Tensor]:
     if tag is None or tag[0] != t._version or tag[1].shape[0] != t.shape[0] or tag[1].device != t.device:
         return None
     return tag[1]
+
+
+def tag_rows(t: torch.Tensor, flags: Optional[torch.Tensor]) -> torch.Tensor:
+    """Remember on the tensor OBJECT that t is zero outside the rows whose flag byte is set (a loss's row-sparse
+    gradient).  t itself stays dense and correct: a consumer that does not look at the tag just reads the zeros."""
+    if flags is not None:
+        t._lkg_rows = (t._version, flags)
+    return t
+
+
+def tagged_rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    tag = getattr(t, "_lkg_rows", None) if t is not None else None
+    if tag is None or tag[0] != t._version or tag[1].shape[0] != t.shape[0] or tag[1].device != t.device:
+        return None
+    return tag[1]
+
+
+def _storage_users(t: torch.Tensor) -> int:
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _RowScratch:
+    """The gradient a loss returns for the N x C entity table touches <= 3B of its rows, yet autograd wants it dense:
+    an N x C zero fill per step (2 GB at 1 M x 512) plus the consumers' reads of those zeros.  Here ONE table per shape
+    is kept all-zero BETWEEN steps: a backward resets the rows the previous one touched (lkg_fill_rows_f32), scatters
+    its own, and tags the result with a per-row flag array so that the aware consumers (act_ln backward, the first
+    layer's transpose SpMM) skip the zero rows.  Only for tables whose gradient is consumed inside the backward pass by
+    this package's own Functions (the caller says so: ``sparse_rows``); as a second guard the table is re-used only when
+    no view of it is alive any more (storage use count back at its baseline), otherwise a fresh one replaces it."""
+
+    _tables: dict = {}
+
+    def __init__(self, like: torch.Tensor):
+        self.buf = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
+        self.flags = torch.zeros(like.shape[0], dtype=torch.uint8, device=like.device)
+        self.users = _storage_users(self.buf)
+        self.dirty: list = []
+
+    @classmethod
+    def acquire(cls, like: torch.Tensor) -> "_RowScratch":
+        key = (like.device, like.shape[0], like.shape[1])
+        ent = cls._tables.get(key)
+        if ent is None or _storage_users(ent.buf) != ent.users:
+            ent = cls._tables[key] = _RowScratch(like)
+        for ids in ent.dirty:
+            N.call("lkg_fill_rows_f32", ids.numel(), ent.buf.shape[1], N.ptr(ids), N.ptr(ent.buf), _ld(ent.buf), 0.0,
+                   N.ptr(ent.flags), 0, _stream())
+        ent.dirty = []
+        return ent
+
+    def mark(self, *id_lists: torch.Tensor):
+        for ids in id_lists:
+            N.call("lkg_fill_rows_f32", ids.numel(), 0, N.ptr(ids), None, 0, 0.0, N.ptr(self.flags), 1, _stream())
+            self.dirty.append(ids)
+
+    def table(self) -> torch.Tensor:
+        """A fresh view per hand-out: while autograd (or anybody) holds it, the storage count shows it."""
+        return tag_rows(self.buf.view(self.buf.shape), self.flags)
+
+
+def _loss_grad_table(emb: torch.Tensor, sparse_rows: bool, *id_lists: torch.Tensor) -> torch.Tensor:
+    """The all-zero N x C table a loss backward scatters its rows ``id_lists`` (int64, contiguous) into."""
+    if not sparse_rows:
+        return torch.zeros_like(emb, memory_format=torch.contiguous_format)
+    ent = _RowScratch.acquire(emb)
+    ent.mark(*id_lists)
+    return ent.table()
 
 
 def row_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
@@ -380,7 +448,8 @@ class _AggregateKeep(Function):
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
         g_side = _f32_rows(g_side)
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
-                        add_self=g_side if ctx.plus_self else None, add2=g_kept), None, None, None, None, None
+                        add_self=g_side if ctx.plus_self else None, add2=g_kept,
+                        add2_rows=tagged_rows(g_kept)), None, None, None, None, None
 
 
 def aggregate_keep(ego, g: KGStructure, val, val_t, plus_self: bool = False, keep_dst: Optional[torch.Tensor] = None):
@@ -570,6 +639,7 @@ class _ActLayerNorm(Function):
         none = (None,) * 10
         if gy is None and gyn is None:
             return none
+        gyn_rows = tagged_rows(gyn)      # a loss's row-sparse gradient: the kernel skips the zero rows
         gy = _f32_rows(gy) if gy is not None else None
         gyn = _f32_rows(gyn) if gyn is not None else None
         gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
@@ -579,7 +649,7 @@ class _ActLayerNorm(Function):
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               float(drop_p), int(seed), N.ptr(rm), _stream())
+               float(drop_p), int(seed), N.ptr(rm), N.ptr(gyn_rows), _stream())
         return (tag_rowmax(gz, rm), gg, gb) + none[3:]
 
 
@@ -624,7 +694,8 @@ class _AssembleCat(Function):
     @staticmethod
     def backward(ctx, g):
         o = ctx.offsets
-        return (None, *[g[:, o[k]:o[k + 1]] for k in range(len(o) - 1)])
+        rows = tagged_rows(g)            # the column slices of a row-sparse gradient are row-sparse
+        return (None, *[tag_rows(g[:, o[k]:o[k + 1]], rows) for k in range(len(o) - 1)])
 
 
 def assemble_cat(holder: CatBuffer, parts: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -748,9 +819,10 @@ class _TransELoss(Function):
     """model_bce.py:329-368 on table rows."""
 
     @staticmethod
-    def forward(ctx, emb, relemb, h, r, pt, nt, lam, keep):
+    def forward(ctx, emb, relemb, h, r, pt, nt, lam, keep, sparse_rows):
         _need_gpu(emb, relemb, h, r, pt, nt)
         emb, relemb = _f32_rows(emb), _f32_rows(relemb)
+        ctx.sparse_rows = bool(sparse_rows)
         if emb.shape[1] != relemb.shape[1]:
             raise ValueError(f"TransE scoring needs entity-side width == relation_dim ({emb.shape[1]} vs "
                              f"{relemb.shape[1]})")
@@ -772,16 +844,18 @@ class _TransELoss(Function):
     def backward(ctx, gl):
         emb, relemb, h, r, pt, nt, buf = ctx.saved_tensors
         gl = gl.contiguous().float()
-        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        g_emb = _loss_grad_table(emb, ctx.sparse_rows, h, pt, nt)
         g_rel = torch.zeros_like(relemb, memory_format=torch.contiguous_format)
         N.call("lkg_transe_score_bwd_f32", h.numel(), emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(relemb), _ld(relemb),
                N.ptr(h), N.ptr(r), N.ptr(pt), N.ptr(nt), N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl),
                N.ptr(g_emb), _ld(g_emb), N.ptr(g_rel), _ld(g_rel), _stream())
-        return g_emb, g_rel, None, None, None, None, None, None
+        return g_emb, g_rel, None, None, None, None, None, None, None
 
 
-def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None):
-    return _TransELoss.apply(emb, relemb, h, r, pos_t, neg_t, lam, keep)
+def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None, sparse_rows: bool = False):
+    """sparse_rows: the gradient of ``emb`` is consumed inside the backward pass by this package's Functions only
+    (the model's concatenated table), so it may be the shared all-zero table of _RowScratch instead of a fresh fill."""
+    return _TransELoss.apply(emb, relemb, h, r, pos_t, neg_t, lam, keep, sparse_rows)
 
 
 # ----------------------------------------------------------------------------- K7+K8 TransR scoring
@@ -813,8 +887,9 @@ class _TransRLoss(Function):
     projected ONCE per group: 2 (2 + K) / K B C D flops instead of 6 B C D."""
 
     @staticmethod
-    def forward(ctx, emb, relemb, trans_m, h, r, pt, nt, lam, keep, group):
+    def forward(ctx, emb, relemb, trans_m, h, r, pt, nt, lam, keep, group, sparse_rows):
         _need_gpu(emb, relemb, trans_m, h, r, pt, nt)
+        ctx.sparse_rows = bool(sparse_rows)
         emb, relemb = _f32_rows(emb), _f32_rows(relemb)
         trans_m = trans_m.contiguous()
         n_rel, c, dout = trans_m.shape
@@ -882,7 +957,7 @@ class _TransRLoss(Function):
                _ld(relemb), N.ptr(rs), N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl), N.ptr(gp),
                N.ptr(gp[n_g:]), N.ptr(gp[2 * n_g:]), dout, N.ptr(g_rel), _ld(g_rel), _stream())
         g_w = torch.empty_like(trans_m)
-        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        g_emb = _loss_grad_table(emb, ctx.sparse_rows, hg, pg, nt)
         gx = torch.empty((max(b, n_g), c), dtype=torch.float32, device=dev)
         parts = ((hg, perm, seg, 0, n_g), (pg, perm, seg, n_g, n_g), (nt, perm_n, seg_n, 2 * n_g, b))
         for i, (ids, pm, sg, off, rows) in enumerate(parts):
@@ -893,11 +968,11 @@ class _TransRLoss(Function):
             _grouped(1, sg, rows, gi, trans_m, gx[:rows], 0, c, dout, False, True, 0.0, stride_b=c * dout)
             N.call("lkg_scatter_add_rows_f32", rows, c, N.ptr(gx), c, N.ptr(ids), N.ptr(pm), N.ptr(g_emb),
                    _ld(g_emb), _stream())
-        return g_emb, g_rel, g_w, None, None, None, None, None, None, None
+        return g_emb, g_rel, g_w, None, None, None, None, None, None, None, None
 
 
-def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group: int = 1):
-    return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep, group)
+def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group: int = 1, sparse_rows: bool = False):
+    return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep, group, sparse_rows)
 
 
 # ----------------------------------------------------------------------------- f1 fine-tuning head
@@ -905,9 +980,10 @@ class _DotLoss(Function):
     """model.py:316-348: dot-product BPR loss on table rows."""
 
     @staticmethod
-    def forward(ctx, emb, h, pt, nt, lam):
+    def forward(ctx, emb, h, pt, nt, lam, sparse_rows):
         _need_gpu(emb, h, pt, nt)
         emb = _f32_rows(emb)
+        ctx.sparse_rows = bool(sparse_rows)
         h, pt, nt = _i64(h), _i64(pt), _i64(nt)
         b = h.numel()
         buf = torch.empty((4, b), dtype=torch.float32, device=emb.device)
@@ -923,14 +999,14 @@ class _DotLoss(Function):
     def backward(ctx, gl):
         emb, h, pt, nt, buf = ctx.saved_tensors
         gl = gl.contiguous().float()
-        g_emb = torch.zeros_like(emb, memory_format=torch.contiguous_format)
+        g_emb = _loss_grad_table(emb, ctx.sparse_rows, h, pt, nt)
         N.call("lkg_dot_score_bwd_f32", h.numel(), emb.shape[1], N.ptr(emb), _ld(emb), N.ptr(h), N.ptr(pt), N.ptr(nt),
                N.ptr(buf[0]), N.ptr(buf[1]), float(ctx.lam), N.ptr(gl), N.ptr(g_emb), _ld(g_emb), _stream())
-        return g_emb, None, None, None, None
+        return g_emb, None, None, None, None, None
 
 
-def dot_loss(emb, h, pos_t, neg_t, lam):
-    return _DotLoss.apply(emb, h, pos_t, neg_t, lam)
+def dot_loss(emb, h, pos_t, neg_t, lam, sparse_rows: bool = False):
+    return _DotLoss.apply(emb, h, pos_t, neg_t, lam, sparse_rows)
 
 
 # ----------------------------------------------------------------------------- f1 MLP head

@@ -1334,3 +1334,100 @@ def test_bench_prints_one_contract_line(gpu_device):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+# ----------------------------------------------------------------------------- the loss's row-sparse table gradient
+@pytest.mark.parametrize("scoring,layers,gate", [("transr", 1, None), ("transe", 2, "mul")])
+def test_loss_row_scratch_equals_a_fresh_zero_table(L, ops, O, gpu_device, scoring, layers, gate):
+    """The shared all-zero gradient table (ops._RowScratch: rows of the previous step reset, row flags for act_ln backward
+    and the first layer's transpose SpMM) against a zeros_like table per step, three different batches in a row."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e, dim = 20_000, 150_000, 64
+    h, t, r = make_kg(n, e, seed=5)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else dim * (layers + 1), conv_dim=dim,
+                        n_conv_layers=layers, aggregation_type="gcn", use_num_lit=gate == "mul",
+                        use_txt_lit=gate == "mul", txt_lit_dim=300, kg_l2loss_lambda=1e-4, device=gpu_device)
+    torch.manual_seed(3)
+    num = torch.rand(n, 2) if gate else None
+    txt = torch.randn(n, 300) if gate else None
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), num, txt, scoring=scoring).to(gpu_device).eval()
+    assert m._table_grad_stays_inside.__func__ is L.LiteralKG._table_grad_stays_inside
+    ops._RowScratch._tables.clear()
+
+    def grads(batch, sparse):
+        m.zero_grad(set_to_none=True)
+        m._table_grad_stays_inside = (lambda: m.gat_rows is None) if sparse else (lambda: False)
+        m(*batch, device=gpu_device, mode="pre_training").backward()
+        return {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    try:
+        for seed in (9, 10, 11):
+            batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 150, 3, seed=seed)]
+            got, want = grads(batch, True), grads(batch, False)
+            assert got.keys() == want.keys()
+            for k in want:     # same kernels on the same values; only the order of the float atomics differs (a stale or
+                scale = float(want[k].abs().max()) + 1e-30      # missing row would show at 1e-3 .. 1 of the scale)
+                assert float((got[k] - want[k]).abs().max()) <= 5e-5 * scale, k
+        (ent,) = ops._RowScratch._tables.values()
+        assert int(ent.flags.sum()) > 0 and ops._storage_users(ent.buf) == ent.users    # nothing holds a view any more
+        held = ent.table()                                   # somebody keeps the gradient: the table must not be re-used
+        ent2 = ops._RowScratch.acquire(ent.buf)
+        assert ent2 is not ent and float(ent2.buf.abs().sum()) == 0.0
+        del held
+        ent3 = ops._RowScratch.acquire(ent.buf)
+        assert ent3 is ent2
+        ops._RowScratch._tables[(ent.buf.device, *ent.buf.shape)] = ent
+        assert len(ent.dirty) == 3                           # the first table: its touched rows are reset on re-use
+        assert ops._RowScratch.acquire(ent.buf) is ent
+        assert float(ent.buf.abs().sum()) == 0.0 and int(ent.flags.sum()) == 0
+    finally:
+        del m._table_grad_stays_inside
+        ops._RowScratch._tables.clear()
+
+
+def test_row_flag_consumers_skip_exactly_the_zero_rows(ops, gpu_device):
+    """lkg_fill_rows_f32 + the row-flag forms of act_ln backward and of the SpMM's second addend against the dense forms."""
+    from literalkg_amd import _native as N
+    from literalkg_amd.graph import KGStructure
+    rng = np.random.default_rng(2)
+    n, d = 3000, 96
+    ids = torch.from_numpy(rng.choice(n, 40)).to(gpu_device)             # with duplicates
+    table = torch.ones(n, d + 4, device=gpu_device)
+    flags = torch.zeros(n, dtype=torch.uint8, device=gpu_device)
+    N.call("lkg_fill_rows_f32", ids.numel(), d, N.ptr(ids), N.ptr(table), table.stride(0), 0.0, N.ptr(flags), 1, None)
+    want = torch.ones(n, d + 4)
+    want[ids.cpu(), :d] = 0
+    assert torch.equal(table.cpu(), want)
+    wf = torch.zeros(n, dtype=torch.uint8)
+    wf[ids.cpu()] = 1
+    assert torch.equal(flags.cpu(), wf)
+    # act_ln backward: g_yn zero outside the flagged rows, with and without a dense g_y
+    z = torch.randn(n, d, device=gpu_device, requires_grad=True)
+    gamma = torch.rand(d, device=gpu_device, requires_grad=True)
+    beta = torch.randn(d, device=gpu_device, requires_grad=True)
+    gyn = torch.zeros(n, d, device=gpu_device)
+    gyn[ids] = torch.randn(ids.numel(), d, device=gpu_device)
+    gy = torch.randn(n, d, device=gpu_device)
+    for use_gy in (False, True):
+        res = []
+        for tagged in (False, True):
+            y, yn = ops.act_layernorm(z, gamma, beta)
+            g2 = ops.tag_rows(gyn.clone(), flags) if tagged else gyn
+            res.append(torch.autograd.grad([y, yn] if use_gy else [yn], [z, gamma, beta], [gy, g2] if use_gy else [g2]))
+        for a, b in zip(*res):
+            assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())   # gamma / beta: atomics
+        assert torch.equal(res[0][0], res[1][0])
+    # SpMM second addend
+    h, t = rng.integers(0, n, 20000), rng.integers(0, n, 20000)
+    g = KGStructure.from_triples(n, h, t, np.zeros_like(h), device=gpu_device)
+    val = torch.rand(g.nnz, device=gpu_device)
+    x = torch.randn(n, d, device=gpu_device)
+    for dd in (d, 32):
+        a = ops.spmm_raw(g.rowptr, g.col, val, x[:, :dd], n, add2=gyn[:, :dd])
+        b = ops.spmm_raw(g.rowptr, g.col, val, x[:, :dd], n, add2=gyn[:, :dd], add2_rows=flags)
+        assert torch.equal(a, b)
+        junk = torch.full((n, dd), float("nan"), device=gpu_device)      # unflagged rows are not even read
+        junk[ids] = gyn[ids][:, :dd]
+        c = ops.spmm_raw(g.rowptr, g.col, val, x[:, :dd], n, add2=junk, add2_rows=flags)
+        assert torch.equal(a, c)
