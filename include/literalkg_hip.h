@@ -361,6 +361,12 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
 
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
+/* out_w[c, j] = sum_r x[r,c] * w[r,j] for a NARROW w (1 <= n_w <= 8 columns) and, when out_sum != NULL,
+ * out_sum[c] = sum_r x[r,c] in the same pass: the weight gradient of a Linear's narrow input panel (gate.py:22-25: the
+ * 2 numeric literals) together with its bias gradient -- one read of x instead of a long-k GEMM that would spend a
+ * 128-wide tile on n_w columns, plus a column-sum pass.  Both outputs are overwritten (f32 atomics inside).     */
+int lkg_colsum_weighted_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *w, int64_t ldw,
+                            int32_t n_w, float *out_sum, float *out_w, int64_t ld_out_w, void *stream);
 
 /* Small element-wise steps of the layers (row-major n x d, row strides in elements):
  *   op 0  out = alpha * a + beta * b   (b NULL: alpha * a + beta)   GCNII residual mix, model.py:94-96; 'gin' sums

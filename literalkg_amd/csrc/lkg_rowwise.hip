@@ -473,7 +473,73 @@ __global__ __launch_bounds__(256) void colsum_kernel(long n, int d, const float 
         atomicAdd(out + c, (s0 + s1) + (s2 + s3));
     }
 }
+
+// out_w[c, j] = sum_i x[i, c] * w[i, j] (j < NW <= 8) and, when asked, out_sum[c] = sum_i x[i, c] in the SAME pass over x:
+// the weight gradient of a Linear's NARROW input panel (the 2-wide numeric literals of the gate: a long-k GEMM would
+// spend a whole 128-wide MFMA tile and a full read of x on two columns) together with the bias gradient.
+template <int NW>
+__global__ __launch_bounds__(256) void colsum_weighted_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                                               const float *__restrict__ w, long ldw,
+                                                               float *__restrict__ out_sum, float *__restrict__ out_w,
+                                                               long ld_out, long rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float s[2] = {0.f, 0.f}, sw[2][NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) sw[0][j] = sw[1][j] = 0.f;
+        long r = r0;
+        for (; r + 4 <= r1; r += 4) {            // four rows in flight per thread; w[r, :] is block-uniform (scalar loads)
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[(r + u) * ldx + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s[u & 1] += v[u];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) sw[u & 1][j] = fmaf(v[u], w[(r + u) * ldw + j], sw[u & 1][j]);
+            }
+        }
+        for (; r < r1; ++r) {
+            const float v = x[r * ldx + c];
+            s[0] += v;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) sw[0][j] = fmaf(v, w[r * ldw + j], sw[0][j]);
+        }
+        if (out_sum) atomicAdd(out_sum + c, s[0] + s[1]);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) atomicAdd(out_w + c * ld_out + j, sw[0][j] + sw[1][j]);
+    }
+}
 }  // namespace
+
+extern "C" int lkg_colsum_weighted_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *w, int64_t ldw,
+                                       int32_t n_w, float *out_sum, float *out_w, int64_t ld_out_w, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && n_w >= 1 && n_w <= 8 && ldw >= n_w && ld_out_w >= n_w && out_w,
+                "lkg_colsum_weighted_f32: bad arguments (1 <= n_w <= 8)");
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = !out_sum || hipMemsetAsync(out_sum, 0, sizeof(float) * d, s) == hipSuccess;
+    ok = ok && (ld_out_w == n_w ? hipMemsetAsync(out_w, 0, sizeof(float) * d * n_w, s)
+                                : hipMemset2DAsync(out_w, sizeof(float) * ld_out_w, 0, sizeof(float) * n_w, d, s)) == hipSuccess;
+    if (!ok) {
+        lkg_set_error("lkg_colsum_weighted_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x && w, "lkg_colsum_weighted_f32: null pointer");
+    const long blocks = std::min<int64_t>((n + 63) / 64, 2048);
+    const long rpb = (n + blocks - 1) / blocks;
+#define LKG_CSW(NW)                                                                                                  \
+    case NW:                                                                                                         \
+        hipLaunchKernelGGL(colsum_weighted_kernel<NW>, dim3((unsigned)blocks), dim3(256), 0, s, (long)n, d, x,       \
+                           (long)ldx, w, (long)ldw, out_sum, out_w, (long)ld_out_w, rpb);                            \
+        break;
+    switch (n_w) {
+        LKG_CSW(1) LKG_CSW(2) LKG_CSW(3) LKG_CSW(4) LKG_CSW(5) LKG_CSW(6) LKG_CSW(7) LKG_CSW(8)
+    }
+#undef LKG_CSW
+    LKG_CHECK_LAUNCH("lkg_colsum_weighted_f32");
+    return LKG_OK;
+}
 
 extern "C" int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream) {
     LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && out, "lkg_colsum_f32: bad arguments");

@@ -154,6 +154,37 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+NARROW_PANEL = 8               # input panels this narrow take their weight gradient from lkg_colsum_weighted_f32
+
+
+def narrow_weight_grad(gy: torch.Tensor, panel: torch.Tensor, want_sum: bool):
+    """(gy^T @ panel  [d x n_w], column sums of gy or None) in ONE pass over gy, for a panel of <= NARROW_PANEL columns."""
+    gy, panel = _f32_rows(gy), _f32_rows(panel)
+    d, n_w = gy.shape[1], panel.shape[1]
+    gw = torch.empty((d, n_w), dtype=torch.float32, device=gy.device)
+    gs = torch.empty(d, dtype=torch.float32, device=gy.device) if want_sum else None
+    N.call("lkg_colsum_weighted_f32", gy.shape[0], d, N.ptr(gy), _ld(gy), N.ptr(panel), _ld(panel), n_w, N.ptr(gs),
+           N.ptr(gw), n_w, _stream())
+    return gw, gs
+
+
+def weight_grads(gy: torch.Tensor, panels: Sequence[torch.Tensor], needed: Sequence[bool], want_sum: bool):
+    """([gy^T @ p for p in panels] (None where not needed), column sums of gy or None): the long-k engine for the wide
+    panels, the narrow ones riding on the bias gradient's pass over gy."""
+    gws = [None] * len(panels)
+    gs = None
+    for i, p in enumerate(panels):
+        if needed[i] and p.shape[1] <= NARROW_PANEL and gy.shape[0] >= 2048:
+            gws[i], s_ = narrow_weight_grad(gy, p, want_sum and gs is None)
+            gs = s_ if s_ is not None else gs
+    if want_sum and gs is None:
+        gs = colsum(gy)
+    for i, p in enumerate(panels):
+        if needed[i] and gws[i] is None:
+            gws[i] = gemm(gy, p, trans_a=True)
+    return gws, gs
+
+
 # ----------------------------------------------------------------------------- tall GEMM (f16 x 2 engine)
 import ctypes as _C
 import os as _os
@@ -484,8 +515,7 @@ class _MultiLinear(Function):
         saved = ctx.saved_tensors
         xs, ws = saved[:n], saved[n:]
         gy = _f32_rows(gy)
-        gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[0]) else None
-        gxs, gws = [], []
+        gxs = []
         rm = None
         for i in range(n):
             if not ctx.needs_input_grad[2 + i]:
@@ -495,8 +525,7 @@ class _MultiLinear(Function):
                 gxs.append(gemm_tall((gy,), ((ws[i],),), False, rowmax=rm))
             else:
                 gxs.append(gemm(gy, ws[i]))
-        for i in range(n):
-            gws.append(gemm(gy, xs[i], trans_a=True) if ctx.needs_input_grad[2 + n + i] else None)
+        gws, gb = weight_grads(gy, xs, ctx.needs_input_grad[2 + n:2 + 2 * n], ctx.has_bias and ctx.needs_input_grad[0])
         return (gb, None, *gxs, *gws)
 
 
@@ -795,12 +824,16 @@ class _FusedGate(Function):
             else:
                 g_x = gemm(ggp, wgs[0], beta=1.0, out=gx)
                 g_x = gemm(gzp, wzs[0], beta=1.0, out=g_x)
-        gb_g = colsum(ggp) if (ctx.has_bias and need[1]) else None
-        gb_z = colsum(gzp) if (ctx.has_bias and need[2]) else None
+        # weight and bias gradients of both projections from the side-by-side buffer: [g_gpre | g_zpre]^T @ panel is
+        # [2d x k]: rows :d are g's, rows d: gate_*'s (one long-k product per panel reads the panel once)
         panels = (x,) + tuple(lits)
         base = 6 + nl
-        g_wg = [gemm(ggp, panels[i], trans_a=True) if need[base + i] else None for i in range(nl + 1)]
-        g_wz = [gemm(gzp, panels[i], trans_a=True) if need[base + nl + 1 + i] else None for i in range(nl + 1)]
+        want = [need[base + i] or need[base + nl + 1 + i] for i in range(nl + 1)]
+        gws, gb = weight_grads(gpz, panels, want, ctx.has_bias and (need[1] or need[2]))
+        g_wg = [gws[i][:d] if need[base + i] else None for i in range(nl + 1)]
+        g_wz = [gws[i][d:] if need[base + nl + 1 + i] else None for i in range(nl + 1)]
+        gb_g = gb[:d] if (gb is not None and need[1]) else None
+        gb_z = gb[d:] if (gb is not None and need[2]) else None
         return (None, gb_g, gb_z, None, None, g_x, *([None] * nl), *g_wg, *g_wz)
 
 

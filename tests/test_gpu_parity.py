@@ -1431,3 +1431,31 @@ def test_row_flag_consumers_skip_exactly_the_zero_rows(ops, gpu_device):
         junk[ids] = gyn[ids][:, :dd]
         c = ops.spmm_raw(g.rowptr, g.col, val, x[:, :dd], n, add2=junk, add2_rows=flags)
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("n_w,d,n", [(1, 64, 5000), (2, 512, 70_001), (3, 100, 2048), (8, 256, 33_333)])
+def test_narrow_panel_weight_gradient_and_bias_in_one_pass(ops, gpu_device, n_w, d, n):
+    """lkg_colsum_weighted_f32 (gy^T @ narrow panel + column sums of gy) against f64, on strided views."""
+    torch.manual_seed(n_w)
+    gy = torch.randn(n, d + 8, device=gpu_device)[:, 4:4 + d]
+    w = torch.rand(n, n_w + 3, device=gpu_device)[:, 1:1 + n_w]
+    gw, gs = ops.narrow_weight_grad(gy, w, True)
+    want_w = gy.double().t() @ w.double()
+    want_s = gy.double().sum(0)
+    scale_w = float((gy.double().abs().t() @ w.double().abs()).max())
+    assert gw.shape == (d, n_w) and float((gw.double() - want_w).abs().max()) <= 2e-6 * scale_w
+    assert float((gs.double() - want_s).abs().max()) <= 2e-6 * float(gy.double().abs().sum(0).max())
+    gw2, none = ops.narrow_weight_grad(gy, w, False)
+    assert none is None and float((gw2 - gw).abs().max()) <= 2e-6 * scale_w
+    # through the Linear: y = x1 w1^T + x2 w2^T + b with a narrow second panel
+    x1 = torch.randn(n, 32, device=gpu_device, requires_grad=True)
+    w1 = torch.randn(d, 32, device=gpu_device, requires_grad=True)
+    w2 = torch.randn(d, n_w, device=gpu_device, requires_grad=True)
+    b = torch.randn(d, device=gpu_device, requires_grad=True)
+    y = ops.multi_linear([x1, w.contiguous()], [w1, w2], b)
+    g = torch.randn(n, d, device=gpu_device)
+    got = torch.autograd.grad(y, [w1, w2, b], g)
+    refs = torch.autograd.grad((x1.double() @ w1.double().t() + w.double() @ w2.double().t() + b.double()), [w1, w2, b],
+                               g.double())
+    for a, r in zip(got, refs):
+        assert float((a.double() - r).abs().max()) <= 1e-5 * float(r.abs().max())
