@@ -20,9 +20,14 @@
 // blocks of 32 so that one lane holds g[row, c] and z[row, c]: the blend (gate.py:24-26) happens in the epilogue.
 //
 // Tile: 128 rows x BN columns (BN = 256: a layer's whole width, A is read and split ONCE; 128 for narrow outputs),
-// 16-k steps, 2 x BN/64 waves of 64 x 64, double-buffered LDS planes, one barrier per step: barrier -> split + write
-// tile t+1 -> re-issue the loads of tile t+2 -> 12 MFMAs of tile t.  B arrives as ready-made fp16 planes (prepared once
-// per call in the caller's workspace, an exact image of the LDS tile).
+// 16-k steps, 2 x BN/64 waves of 64 x 64, double-buffered LDS planes, one barrier per step.  Every load of the k loop is
+// an LDS-DMA (global_load_lds_dwordx4, no VGPR destination, waits counted by hand): B arrives as ready-made fp16 planes
+// (prepared once per call in the caller's workspace, an exact image of the LDS tile) straight into the other buffer; A's
+// raw f32 windows land in a 3-deep ring, two steps ahead of their use, and the thread that asked for a window reads it
+// back, splits it and writes its piece of the planes IN THE SHADOW of the step's 12 MFMAs (the split is cut into pieces
+// pinned between them: an MFMA holds the matrix pipe for 32 cycles but the issue port for 8).
+// Per workgroup at 1 M x 256 x 256 (s_memtime stamps, 1.8-1.95 GHz under this load): prologue 7-8 k cycles (one HBM
+// round trip), k loop 42 k (16 steps of 2.6 k with two workgroups per CU: the matrix pipe 58 % busy), epilogue 11-13 k.
 #include <stdlib.h>
 #include <string.h>
 
@@ -164,7 +169,9 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
 // subnormals for elements below 2^-17 of their row maximum) and  a'.b' = hi_a hi_b + hs_a mid_b + mid_a hs_b.  64
 // accumulator registers less per lane: three 4-wave workgroups (or two 8-wave ones) share a CU and their phases overlap.
 template <int BN, int EPI, bool ONE>
-__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(ONE ? (BN == 128 ? 3 : 4) : 2, ONE ? (BN == 128 ? 3 : 4) : 2)))
+// (the gate's x stash leaves room for ONE 256-column workgroup per CU whatever its registers: no reason to squeeze it)
+__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu((ONE && !(EPI == EPI_GATE && BN == 256)) ? (BN == 128 ? 3 : 4) : 2,
+                                                                      (ONE && !(EPI == EPI_GATE && BN == 256)) ? (BN == 128 ? 3 : 4) : 2)))
 void gemm_tall_kernel(TallArgs g) {
     constexpr int NT = 2 * BN;                    // threads
     constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
@@ -174,9 +181,13 @@ void gemm_tall_kernel(TallArgs g) {
     // ONE dynamic LDS object: staging planes, the tile's row exponents, and (gate) the stash of the x values the blend
     // needs -- x is the gate's first K-panel, so the columns of this tile pass through the staging registers anyway
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-    int *ea_s = reinterpret_cast<int *>(smem + 2 * BUF);
+    constexpr int RING = 3;                        // raw A tiles (f32, as loaded) in flight
+    float *raw_s = reinterpret_cast<float *>(smem + 2 * BUF);
+    int *ea_s = reinterpret_cast<int *>(raw_s + RING * TM * TK);
+    int *eb_s = ea_s + TM;                         // exponents / bias of this tile's BN stacked columns: fetched at the start,
+    float *bias_s = reinterpret_cast<float *>(eb_s + BN);   //   read in the epilogue without a global round trip
     constexpr int XP = BN / 2 + 4;                 // stash pitch (floats): the tile's output columns + 4, conflict-free 16-byte writes
-    float *xstash = reinterpret_cast<float *>(smem + 2 * BUF + 2 * TM);
+    float *xstash = bias_s + BN;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / (BN / 64), wn = wave % (BN / 64);
@@ -193,6 +204,19 @@ void gemm_tall_kernel(TallArgs g) {
     const int n0 = tn * BN;
 
     if (t < TM) ea_s[t] = scale_exponent(g.a_rowmax[min(m0 + t, g.m - 1)]);
+    if (t < BN) {
+        eb_s[t] = g.eb[n0 + t];
+        float bv = 0.f;
+        if (g.bias) {
+            if constexpr (EPI == EPI_GATE) {       // stacked column s of the tile: group (s / 32) & 1, output column (s / 64) * 32 + s % 32
+                const int d = g.n / 2, oc = min((n0 >> 1) + (t >> 6) * 32 + (t & 31), d - 1);
+                bv = g.bias[((t >> 5) & 1) * d + oc];
+            } else {
+                bv = g.bias[min(n0 + t, g.n - 1)];
+            }
+        }
+        bias_s[t] = bv;
+    }
     const int arow = t / TPR, akc = t % TPR;                 // this thread's row / k chunk of the A tile
     const long grow = min(m0 + arow, g.m - 1);               // clamped: rows past m are computed and never stored
     const int ea = scale_exponent(g.a_rowmax[grow]);
@@ -228,137 +252,276 @@ void gemm_tall_kernel(TallArgs g) {
 #undef LKG_PANEL
     const int n_tiles = g.ktiles_total;
 
-    float av[EPT];
-    uint4 qb0, qb1;
+    typedef __attribute__((address_space(3))) void lds_void;
     const uint4 *bsrc = reinterpret_cast<const uint4 *>(g.bp) + (long)tn * g.ktiles_total * (2 * BPL / 8) + t;
 
-    // the tile the next fetch reads: (panel, tile inside the panel) walked incrementally -- a closed form
-    // (gt >= kt1 ? ... : ...) became a lookup table in private memory
-    int f_gt = 0, f_tk = 0, f_panel = 0, f_nt = g.ktiles[0], f_kp = kw0;
+    // ---- loads: LDS-DMA only (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR destination).  B's planes are
+    // ready-made LDS images, so a tile is a straight copy into the other buffer; A's raw f32 windows go into a RING-deep
+    // ring of which every thread reads back exactly the 16-byte pieces it requested itself (no cross-thread hazard, the
+    // ring only replaces the registers a deeper prefetch would need).  The waits are counted by hand (vmcnt is in issue
+    // order): per step the loads are issued as [B tile, A windows], the top of a step needs everything but the newest A.
+    constexpr int NA = EPT / 4;                    // A windows (LDS-DMA instructions) per thread per tile
+    // the tile the next A fetch reads: (panel, tile inside the panel) walked incrementally -- a closed form
+    // (gt >= kt1 ? ... : ...) became a lookup table in private memory.  The staging side walks the same sequence
+    // RING - 1 tiles behind (wave-uniform scalars), the per-thread window shifts travel in a small bit FIFO.
+    int f_gt = 0, f_tk = 0, f_panel = 0, f_nt = g.ktiles[0];
     unsigned long f_rowp = rowp0, f_lastw = lastw0;
-    float4u raw[EPT / 4];                          // the windows as loaded; shifted / masked when they are staged
-    int raw_sh[EPT / 4], raw_k0 = 0, raw_kp = 0;
-    bool raw_first = true;                         // the staged tile belongs to panel 0
-    auto fetch_tile = [&]() {
-        raw_k0 = f_tk * TK + akc * EPT;
-        raw_kp = f_kp;
-        raw_first = f_panel == 0;
+    int s_gt = 0, s_tk = 0, s_panel = 0, s_nt = g.ktiles[0], s_kp = kw0;
+    unsigned sh_fifo = 0;                          // 4 bits per tile in flight: 2 per window
+    unsigned long a_ptr[NA];                       // the windows of the tile the next issue_a requests
+    // (all scalar bookkeeping -- the two walks -- happens in plan_a / plan_stage, ahead of the step's one basic block of
+    // barrier, DMA issue, MFMAs and split: a branch inside would keep the scheduler from mixing the split into the MFMAs)
+    auto plan_a = [&](int fifo_pos) {
 #pragma unroll
-        for (int q = 0; q < EPT / 4; ++q) {
+        for (int q = 0; q < NA; ++q) {
             const unsigned long want = f_rowp + 4ul * (unsigned long)(f_tk * TK + 4 * q);
-            const unsigned long ptr = want < f_lastw ? want : f_lastw;
-            raw_sh[q] = (int)((want - ptr) >> 2);       // 0 unless the window was moved back (1..3; more = all masked)
-            raw[q] = *reinterpret_cast<gf4 *>(ptr);
+            a_ptr[q] = want < f_lastw ? want : f_lastw;
+            // 0 unless the window was moved back (1..3 elements; further back = past the panel: masked by k anyway)
+            sh_fifo |= ((unsigned)((want - a_ptr[q]) >> 2) & 3u) << (4 * fifo_pos + 2 * q);
         }
-        const uint4 *src = bsrc + (long)f_gt * (2 * BPL / 8);
-        qb0 = src[0];
-        qb1 = src[BPL / 8];
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads here (sunk towards their use they lose the prefetch)
-        // advance (wave-uniform scalar bookkeeping only; past the last tile the state stays: duplicates are fetched)
+        // advance (wave-uniform scalars only; past the last tile the state stays: duplicates are fetched)
         if (f_gt + 1 < n_tiles) {
             ++f_gt;
             if (++f_tk == f_nt) {
                 f_tk = 0;
                 if (f_panel == 0) {
-                    f_rowp = rowp1; f_lastw = lastw1; f_kp = kw1; f_nt = g.ktiles[1];
+                    f_rowp = rowp1; f_lastw = lastw1; f_nt = g.ktiles[1];
                 } else {
-                    f_rowp = rowp2; f_lastw = lastw2; f_kp = kw2; f_nt = g.ktiles[2];
+                    f_rowp = rowp2; f_lastw = lastw2; f_nt = g.ktiles[2];
                 }
                 ++f_panel;
             }
         }
     };
-    auto stage = [&](_Float16 *D) {               // registers -> LDS image of one tile
+    auto issue_a = [&](int slot) {
+        float *dst = raw_s + slot * (TM * TK) + wave * 256;
 #pragma unroll
-        for (int q = 0; q < EPT / 4; ++q) {       // (here, a whole step after the load was issued: no wait on a fresh load)
-            const float4u v = raw[q];
-            const bool s1 = raw_sh[q] & 1, s2 = raw_sh[q] & 2;   // a barrel shifter of selects (no branch)
+        for (int q = 0; q < NA; ++q)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<gf4 *>(a_ptr[q]), (lds_void *)(dst + q * (NT * 4)), 16, 0, 0);
+    };
+    auto issue_b = [&](int tile_k, _Float16 *D) {
+        typedef __attribute__((address_space(1))) const uint4 gu4;
+        const uint4 *src = bsrc + (long)min(tile_k, n_tiles - 1) * (2 * BPL / 8);
+        uint4 *d = reinterpret_cast<uint4 *>(D + 2 * APL) + wave * 64;
+        __builtin_amdgcn_global_load_lds((gu4 *)src, (lds_void *)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gu4 *)(src + BPL / 8), (lds_void *)(d + BPL / 8), 16, 0, 0);
+    };
+    int st_k0 = 0, st_kp = 0;                      // the tile being staged: first k of this thread's windows, panel width
+    bool st_first = true;                          //   ... and whether it belongs to panel 0 (the gate's x)
+    unsigned st_sh = 0;
+    auto plan_stage = [&]() {
+        st_k0 = s_tk * TK + akc * EPT;
+        st_kp = s_kp;
+        st_first = s_panel == 0;
+        st_sh = sh_fifo;
+        sh_fifo >>= 4;
+        if (s_gt + 1 < n_tiles) {                 // the same walk as plan_a's
+            ++s_gt;
+            if (++s_tk == s_nt) {
+                s_tk = 0;
+                if (s_panel == 0) {
+                    s_kp = kw1; s_nt = g.ktiles[1];
+                } else {
+                    s_kp = kw2; s_nt = g.ktiles[2];
+                }
+                ++s_panel;
+            }
+        }
+    };
+    // The ring is read back with inline asm: a ds_read hipcc can see makes it drain EVERY LDS-DMA in flight first
+    // (s_waitcnt vmcnt(0): it cannot tell which DMA wrote the bytes).  Its own counted lgkmcnt waits stay safe beside
+    // an unseen LDS read (they can only wait for more than they need); the values are tied to ring_wait() below.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 rawv[NA];
+    auto ring_read = [&](int slot) {
+        const unsigned addr = (unsigned)(unsigned long)(lds_void *)(raw_s + slot * (TM * TK) + t * 4);
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(rawv[q]) : "v"(addr + q * (NT * 16)) : "memory");
+    };
+    auto ring_wait = [&]() {
+        if constexpr (NA == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rawv[0]) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rawv[0]), "+v"(rawv[1]) :: "memory");
+    };
+    // One k step: the 12 MFMAs of the tile in S with the split of the NEXT tile (this thread's raw windows in rawv -> its
+    // piece of the fp16 planes in D) cut into pieces that are pinned behind them: an MFMA occupies the matrix pipe for 32
+    // cycles but the wave's issue port for 8 only, so 5-6 single-issue VALU instructions between two MFMAs are free
+    // (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') -- the compiler's own order puts the split behind the last
+    // MFMA, where every instruction of it costs its full issue time.
+#define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto step = [&](const _Float16 *S, _Float16 *D, bool do_stage) {
+        // fragments are fetched where their registers become free (all eight up front would hold 32 registers at once)
+        f16x8 a0[2], b0[2], a1[2], b1[2];
+        auto fa = [&](int i, int pl) { return frag<BN>(S + pl * APL, wm * 64 + i * 32, lane); };
+        auto fb = [&](int j, int pl) { return frag<BN>(S + 2 * APL + pl * BPL, wn * 64 + j * 32, lane); };
+        a0[0] = fa(0, 0); b0[0] = fb(0, 0); b0[1] = fb(1, 0); a0[1] = fa(1, 0);
+        const _Float16 sc = (_Float16)(1.f / 2048.f);
+        f16x8 ahs[2], bhs[2];
+        float e[EPT];
+        fp16x2 hi[EPT / 2], mid[EPT / 2];
+        // ---- the pieces of the split (each a handful of VALU instructions per window)
+        auto p_shift1 = [&]() {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const f32x4 v = rawv[q];
+                const bool s1 = (st_sh >> (2 * q)) & 1;   // a barrel shifter of selects (no branch)
+                e[4 * q] = s1 ? v[1] : v[0]; e[4 * q + 1] = s1 ? v[2] : v[1]; e[4 * q + 2] = s1 ? v[3] : v[2]; e[4 * q + 3] = s1 ? 0.f : v[3];
+            }
+        };
+        auto p_shift2 = [&]() {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const bool s2 = (st_sh >> (2 * q)) & 2;
+                const float w0 = e[4 * q], w1 = e[4 * q + 1], w2 = e[4 * q + 2], w3 = e[4 * q + 3];
+                e[4 * q] = s2 ? w2 : w0; e[4 * q + 1] = s2 ? w3 : w1; e[4 * q + 2] = s2 ? 0.f : w2; e[4 * q + 3] = s2 ? 0.f : w3;
+            }
+        };
+        auto p_mask = [&]() {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int kk = st_k0 + 4 * q;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[4 * q + u] = kk + u < st_kp ? e[4 * q + u] : 0.f;
+            }
+            if constexpr (EPI == EPI_GATE) {      // keep x[rows of the tile, output columns of the tile] for the epilogue
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+                    const int c = st_k0 + 4 * q - (n0 >> 1);
+                    if (st_first && c >= 0 && c < BN / 2)
+                        *reinterpret_cast<float4 *>(xstash + arow * XP + c) =
+                            make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+                }
+            }
+        };
+        auto p_hi = [&]() {
+#pragma unroll
+            for (int u = 0; u < EPT; u += 2) {
+                e[u] = ldexpf(e[u], ea);
+                e[u + 1] = ldexpf(e[u + 1], ea);
+                hi[u / 2] = __builtin_amdgcn_cvt_pkrtz(e[u], e[u + 1]);
+            }
+        };
+        auto p_res = [&]() {
+#pragma unroll
+            for (int u = 0; u < EPT; u += 2) {
+                e[u] = (e[u] - (float)hi[u / 2][0]) * 2048.f;
+                e[u + 1] = (e[u + 1] - (float)hi[u / 2][1]) * 2048.f;
+            }
+        };
+        auto p_mid = [&]() {
+#pragma unroll
+            for (int u = 0; u < EPT; u += 2) mid[u / 2] = __builtin_amdgcn_cvt_pkrtz(e[u], e[u + 1]);
+        };
+        auto p_write = [&]() {
+            _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
+            typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int q = 0; q < EPT; q += 4) {
+                const fp16x4 hv = {hi[q / 2][0], hi[q / 2][1], hi[q / 2 + 1][0], hi[q / 2 + 1][1]};
+                const fp16x4 mv = {mid[q / 2][0], mid[q / 2][1], mid[q / 2 + 1][0], mid[q / 2 + 1][1]};
+                *reinterpret_cast<fp16x4 *>(pa + q) = hv;
+                *reinterpret_cast<fp16x4 *>(pa + APL + q) = mv;
+            }
+        };
+#define LKG_MFMA(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
+        LKG_PIN();
+        if constexpr (ONE) {
+            LKG_MFMA(acc[0][0], a0[0], b0[0]); ahs[0] = a0[0] * sc; b1[0] = fb(0, 1); LKG_PIN();
+            LKG_MFMA(acc[0][1], a0[0], b0[1]); ahs[1] = a0[1] * sc; b1[1] = fb(1, 1); LKG_PIN();
+            LKG_MFMA(acc[1][0], a0[1], b0[0]); bhs[0] = b0[0] * sc; LKG_PIN();
+            LKG_MFMA(acc[1][1], a0[1], b0[1]); bhs[1] = b0[1] * sc; LKG_PIN();
+            LKG_MFMA(acc[0][0], ahs[0], b1[0]); a1[0] = fa(0, 1); a1[1] = fa(1, 1); if (do_stage) p_shift1(); LKG_PIN();
+            LKG_MFMA(acc[0][1], ahs[0], b1[1]); if (do_stage) p_shift2(); LKG_PIN();
+            LKG_MFMA(acc[1][0], ahs[1], b1[0]); if (do_stage) p_mask(); LKG_PIN();
+            LKG_MFMA(acc[1][1], ahs[1], b1[1]); if (do_stage) p_hi(); LKG_PIN();
+            LKG_MFMA(acc[0][0], a1[0], bhs[0]); if (do_stage) p_res(); LKG_PIN();
+            LKG_MFMA(acc[0][1], a1[0], bhs[1]); if (do_stage) p_mid(); LKG_PIN();
+            LKG_MFMA(acc[1][0], a1[1], bhs[0]); if (do_stage) p_write(); LKG_PIN();
+            LKG_MFMA(acc[1][1], a1[1], bhs[1]);
+        } else {
+            LKG_MFMA(acc[0][0], a0[0], b0[0]); b1[0] = fb(0, 1); LKG_PIN();
+            LKG_MFMA(acc[0][1], a0[0], b0[1]); b1[1] = fb(1, 1); LKG_PIN();
+            LKG_MFMA(acc[1][0], a0[1], b0[0]); a1[0] = fa(0, 1); LKG_PIN();
+            LKG_MFMA(acc[1][1], a0[1], b0[1]); a1[1] = fa(1, 1); LKG_PIN();
+            LKG_MFMA(cor[0][0], a0[0], b1[0]); if (do_stage) p_shift1(); LKG_PIN();
+            LKG_MFMA(cor[0][1], a0[0], b1[1]); if (do_stage) p_shift2(); LKG_PIN();
+            LKG_MFMA(cor[1][0], a0[1], b1[0]); if (do_stage) p_mask(); LKG_PIN();
+            LKG_MFMA(cor[1][1], a0[1], b1[1]); if (do_stage) p_hi(); LKG_PIN();
+            LKG_MFMA(cor[0][0], a1[0], b0[0]); if (do_stage) p_res(); LKG_PIN();
+            LKG_MFMA(cor[0][1], a1[0], b0[1]); if (do_stage) p_mid(); LKG_PIN();
+            LKG_MFMA(cor[1][0], a1[1], b0[0]); if (do_stage) p_write(); LKG_PIN();
+            LKG_MFMA(cor[1][1], a1[1], b0[1]);
+        }
+#undef LKG_MFMA
+    };
+#undef LKG_PIN
+    auto stage_only = [&](_Float16 *D) {           // (prologue: the split of tile 0 alone)
+        float e[EPT];
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const f32x4 v = rawv[q];
+            const unsigned sh = st_sh >> (2 * q);
+            const bool s1 = sh & 1, s2 = sh & 2;
             const float w0 = s1 ? v[1] : v[0], w1 = s1 ? v[2] : v[1], w2 = s1 ? v[3] : v[2], w3 = s1 ? 0.f : v[3];
             const float e0 = s2 ? w2 : w0, e1 = s2 ? w3 : w1, e2 = s2 ? 0.f : w2, e3 = s2 ? 0.f : w3;
-            const int kk = raw_k0 + 4 * q;
-            av[4 * q] = kk < raw_kp ? e0 : 0.f;
-            av[4 * q + 1] = kk + 1 < raw_kp ? e1 : 0.f;
-            av[4 * q + 2] = kk + 2 < raw_kp ? e2 : 0.f;
-            av[4 * q + 3] = kk + 3 < raw_kp ? e3 : 0.f;
+            const int kk = st_k0 + 4 * q;
+            e[4 * q] = kk < st_kp ? e0 : 0.f;
+            e[4 * q + 1] = kk + 1 < st_kp ? e1 : 0.f;
+            e[4 * q + 2] = kk + 2 < st_kp ? e2 : 0.f;
+            e[4 * q + 3] = kk + 3 < st_kp ? e3 : 0.f;
         }
-        if constexpr (EPI == EPI_GATE) {          // keep x[rows of the tile, output columns of the tile] for the epilogue
+        if constexpr (EPI == EPI_GATE) {
 #pragma unroll
-            for (int q = 0; q < EPT / 4; ++q) {
-                const int c = raw_k0 + 4 * q - (n0 >> 1);
-                if (raw_first && c >= 0 && c < BN / 2)
-                    *reinterpret_cast<float4 *>(xstash + arow * XP + c) =
-                        make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
+            for (int q = 0; q < NA; ++q) {
+                const int c = st_k0 + 4 * q - (n0 >> 1);
+                if (st_first && c >= 0 && c < BN / 2)
+                    *reinterpret_cast<float4 *>(xstash + arow * XP + c) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
             }
         }
         _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
 #pragma unroll
         for (int q = 0; q < EPT; q += 4) {
             fp16x2 h0, m0_, h1, m1;
-            split2(ldexpf(av[q], ea), ldexpf(av[q + 1], ea), h0, m0_);
-            split2(ldexpf(av[q + 2], ea), ldexpf(av[q + 3], ea), h1, m1);
+            split2(ldexpf(e[q], ea), ldexpf(e[q + 1], ea), h0, m0_);
+            split2(ldexpf(e[q + 2], ea), ldexpf(e[q + 3], ea), h1, m1);
             typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
             const fp16x4 hv = {h0[0], h0[1], h1[0], h1[1]}, mv = {m0_[0], m0_[1], m1[0], m1[1]};
             *reinterpret_cast<fp16x4 *>(pa + q) = hv;
             *reinterpret_cast<fp16x4 *>(pa + APL + q) = mv;
         }
-        uint4 *d = reinterpret_cast<uint4 *>(D + 2 * APL) + t;
-        d[0] = qb0;
-        d[BPL / 8] = qb1;
-    };
-    auto mma = [&](const _Float16 *S) {
-        f16x8 a[2][2], b[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                a[i][pl] = frag<BN>(S + pl * APL, wm * 64 + i * 32, lane);
-                b[i][pl] = frag<BN>(S + 2 * APL + pl * BPL, wn * 64 + i * 32, lane);
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-        if constexpr (ONE) {
-            const _Float16 sc = (_Float16)(1.f / 2048.f);
-            f16x8 ahs[2], bhs[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ahs[i] = a[i][0] * sc;
-                bhs[i] = b[i][0] * sc;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs[i], b[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bhs[j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], cor[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], cor[i][j], 0, 0, 0);
-        }
     };
 
-    // One register set, one barrier per step, no branch in the loop (the accumulators never meet a control-flow join):
-    // step t: barrier (tile t is complete in buffer t & 1, nobody still reads the other one) -> split + write tile t+1
-    // into the other buffer -> re-issue the loads for tile t+2 -> fragment reads + 12 MFMAs of tile t.  Past the last
-    // tile the staged / fetched tile is a duplicate of the last one (in bounds, never read).
-    fetch_tile();
-    stage(smem);
-    fetch_tile();
+    // One barrier per step, no branch in the loop (the accumulators never meet a control-flow join).  Step t: wait for
+    // this wave's B(t) and A(t+1) pieces + its plane writes, barrier (tile t complete in buffer t & 1, nobody still reads
+    // the other one) -> LDS-DMA of B(t+1) into the other buffer and of A(t+3) into the ring slot tile t just left ->
+    // fragment reads + 12 MFMAs of tile t, with the split of tile t+1 (ring -> planes of the other buffer) in their
+    // shadow.  Past the last tile the staged / fetched tiles are duplicates of the last one (in bounds, never read).
+#define LKG_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    issue_b(0, smem);
+    plan_a(0); issue_a(0);
+    plan_a(1); issue_a(1);
+    plan_a(2); issue_a(2);
+    if constexpr (NA == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    plan_stage();
+    ring_read(0);                                  // (its own pieces: no barrier between the DMA and the read-back)
+    ring_wait();
+    stage_only(smem);
+    int slot_f = 0, slot_s = 1;                    // ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged
     for (int gt = 0; gt < n_tiles; ++gt) {
-        __syncthreads();
-        stage(smem + ((gt + 1) & 1) * BUF);
-        fetch_tile();
-        mma(smem + (gt & 1) * BUF);
+        plan_a(2);
+        plan_stage();
+        _Float16 *cur = smem + (gt & 1) * BUF, *nxt = smem + ((gt + 1) & 1) * BUF;
+        if constexpr (NA == 1) LKG_WAIT_BARRIER(1); else LKG_WAIT_BARRIER(2);
+        ring_read(slot_s);
+        issue_b(gt + 1, nxt);
+        issue_a(slot_f);
+        ring_wait();
+        step(cur, nxt, true);
+        slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
+        slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
     }
+#undef LKG_WAIT_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the duplicate tiles still in flight target the ring
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
     // holds ONE column of 16 rows.  Written as it stands that is 16 dword stores per tile (two 128-byte runs per
@@ -395,13 +558,12 @@ void gemm_tall_kernel(TallArgs g) {
         }
     };
     if constexpr (EPI == EPI_PLAIN) {
-        float bias_v[2] = {0.f, 0.f};
+        float bias_v[2];
         int eb_v[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            eb_v[j] = g.eb[col];
-            if (g.bias) bias_v[j] = g.bias[min(col, g.n - 1)];
+            eb_v[j] = eb_s[wn * 64 + j * 32 + (lane & 31)];
+            bias_v[j] = bias_s[wn * 64 + j * 32 + (lane & 31)];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -429,8 +591,8 @@ void gemm_tall_kernel(TallArgs g) {
         const int col = col0 + (lane & 31);
         if (col0 < d) {                                                   // wave-uniform
             const int cc = min(col, d - 1);                               // lanes past d compute on a clamped column, never stored
-            const int ebg = g.eb[n0 + wn * 64 + (lane & 31)], ebz = g.eb[n0 + wn * 64 + 32 + (lane & 31)];
-            const float bg = g.bias ? g.bias[cc] : 0.f, bz = g.bias ? g.bias[d + cc] : 0.f;
+            const int ebg = eb_s[wn * 64 + (lane & 31)], ebz = eb_s[wn * 64 + 32 + (lane & 31)];
+            const float bg = bias_s[wn * 64 + (lane & 31)], bz = bias_s[wn * 64 + 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
@@ -597,7 +759,7 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     auto lds_bytes = [](int bn_, bool gate) {
-        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + TM * 4 + (gate ? TM * (bn_ / 2 + 4) * 4 : 0);
+        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4 + (gate ? TM * (bn_ / 2 + 4) * 4 : 0);
     };
     const int lds = lds_bytes(bn, epilogue == EPI_GATE);
     const bool one = tall_variant() != 0;
