@@ -353,11 +353,13 @@ int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
 int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                            int64_t ldg, const float *zpre, int64_t ldz, float *out, int64_t ldo,
                            void *stream);
-/* activated != 0: gpre / zpre hold tanh(g) / sigmoid(z) (what the fused gate epilogue of lkg_gemm_tall_f32 keeps).   */
+/* activated != 0: gpre / zpre hold tanh(g) / sigmoid(z) (what the fused gate epilogue of lkg_gemm_tall_f32 keeps).
+ * g_pre_rowmax (nullable, float[n], cleared here): max over row i of |g_gpre[i,:]| and |g_zpre[i,:]| -- the row scale of
+ * the two-panel data-gradient GEMM that consumes them (lkg_gemm_tall_f32), without a pass of its own.               */
 int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                            int64_t ldg, const float *zpre, int64_t ldz, const float *g_out,
                            int64_t ldgo, float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg,
-                           float *g_zpre, int64_t ldgz, int32_t activated, void *stream);
+                           float *g_zpre, int64_t ldgz, int32_t activated, float *g_pre_rowmax, void *stream);
 
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);

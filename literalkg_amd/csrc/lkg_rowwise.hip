@@ -291,10 +291,12 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
                                                               const float *__restrict__ g_out, long ldgo,
                                                               float *__restrict__ g_x, long ldgx,
                                                               float *__restrict__ g_gpre, long ldgg,
-                                                              float *__restrict__ g_zpre, long ldgz, int activated) {
+                                                              float *__restrict__ g_zpre, long ldgz, int activated,
+                                                              int *__restrict__ pre_rowmax) {
     const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
     const int c0 = (threadIdx.x & (tpr - 1)) * W;
-    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb) {
+        float rmax = 0.f;
         for (int c = c0; c < d; c += tpr * W) {
             float xv[W], gv[W], zv[W], go[W], ox[W], og[W], oz[W];
             if constexpr (W == 4) {
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
                 ox[k] = go[k] * (1.f - s);
                 og[k] = go[k] * s * (1.f - tg * tg);
                 oz[k] = go[k] * (tg - xv[k]) * s * (1.f - s);
+                rmax = fmaxf(rmax, fmaxf(fabsf(og[k]), fabsf(oz[k])));
             }
             if constexpr (W == 4) {
                 *reinterpret_cast<float4 *>(g_x + r * ldgx + c) = *reinterpret_cast<float4 *>(ox);
@@ -327,6 +330,12 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
                 g_zpre[r * ldgz + c] = oz[0];
             }
         }
+        if (pre_rowmax) {   // max |[g_gpre | g_zpre][r, :]|: the row scale of the data-gradient GEMM over the two (lkg_gemm_tall_f32)
+            const int span = tpr < 64 ? tpr : 64;             // the row's threads inside this wave are consecutive lanes
+            for (int m = 1; m < span; m <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, m, 64));
+            if ((threadIdx.x & (span - 1)) == 0) atomicMax(pre_rowmax + r, __float_as_int(rmax));
+        }
+    }
 }
 
 // threads per row (log2) for a row of `units` access units
@@ -434,10 +443,14 @@ extern "C" int lkg_gate_blend_fwd_f32(int64_t n, int32_t d, const float *x, int6
 extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
                                       int64_t ldg, const float *zpre, int64_t ldz, const float *g_out, int64_t ldgo,
                                       float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg, float *g_zpre,
-                                      int64_t ldgz, int32_t activated, void *stream) {
+                                      int64_t ldgz, int32_t activated, float *g_pre_rowmax, void *stream) {
     LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldg >= d && ldz >= d && ldgo >= d && ldgx >= d && ldgg >= d && ldgz >= d,
                 "lkg_gate_blend_bwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
+    if (g_pre_rowmax && hipMemsetAsync(g_pre_rowmax, 0, sizeof(float) * n, (hipStream_t)stream) != hipSuccess) {
+        lkg_set_error("lkg_gate_blend_bwd_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
     LKG_REQUIRE(x && gpre && zpre && g_out && g_x && g_gpre && g_zpre, "lkg_gate_blend_bwd_f32: null pointer");
     const bool vec = d % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldgo % 4 == 0 && ldgx % 4 == 0 &&
                      ldgg % 4 == 0 && ldgz % 4 == 0 && lkg_aligned16(x) && lkg_aligned16(gpre) && lkg_aligned16(zpre) &&
@@ -447,11 +460,11 @@ extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int6
     if (vec)
         hipLaunchKernelGGL(gate_blend_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
                            d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
-                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated);
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated, reinterpret_cast<int *>(g_pre_rowmax));
     else
         hipLaunchKernelGGL(gate_blend_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n,
                            d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
-                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated);
+                           g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated, reinterpret_cast<int *>(g_pre_rowmax));
     LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_f32");
     return LKG_OK;
 }

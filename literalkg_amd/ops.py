@@ -752,7 +752,7 @@ class _GateBlend(Function):
         n, d = x.shape
         gx, gg, gz = (torch.empty((n, d), dtype=torch.float32, device=x.device) for _ in range(3))
         N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(gpre), _ld(gpre), N.ptr(zpre), _ld(zpre),
-               N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), 0, _stream())
+               N.ptr(go), _ld(go), N.ptr(gx), _ld(gx), N.ptr(gg), _ld(gg), N.ptr(gz), _ld(gz), 0, None, _stream())
         return gx, gg, gz, None
 
 
@@ -814,13 +814,15 @@ class _FusedGate(Function):
         gx = torch.empty((n, d), dtype=torch.float32, device=x.device)
         gpz = torch.empty((n, 2 * d), dtype=torch.float32, device=x.device)      # [g_gpre | g_zpre]
         ggp, gzp = gpz[:, :d], gpz[:, d:]
-        N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
-               _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, _stream())
         need = ctx.needs_input_grad           # (out, bg, bz, n_lit, grad_mode, x, lits..., wgs..., wzs...)
+        tall = need[5] and tall_ok(n, d, (d, d))
+        rm = torch.empty(n, dtype=torch.float32, device=x.device) if tall else None   # row scale of the data-gradient GEMM
+        N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
+               _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, N.ptr(rm), _stream())
         g_x = None
         if need[5]:
-            if tall_ok(n, d, (d, d)):
-                g_x = gemm_tall((ggp, gzp), ((wgs[0], wzs[0]),), False, beta=1.0, out=gx)
+            if tall:
+                g_x = gemm_tall((ggp, gzp), ((wgs[0], wzs[0]),), False, beta=1.0, out=gx, rowmax=rm)
             else:
                 g_x = gemm(ggp, wgs[0], beta=1.0, out=gx)
                 g_x = gemm(gzp, wzs[0], beta=1.0, out=g_x)
