@@ -139,13 +139,17 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
  *   copy_src/copy_dst  copy_dst[i,:] = copy_src[i,:] -- in the forward, that copy itself (the raw entity table into
  *                      column slot 0 of the concatenated table when no gate is configured);
  *   rowmax_out         float[n_rows] (cleared here): max |out[i,:]| -- the row scale the tall GEMM of the layer's
- *                      Linear needs of its input (lkg_gemm_tall_f32), produced while the row is in registers.   */
+ *                      Linear needs of its input (lkg_gemm_tall_f32), produced while the row is in registers;
+ *   x_rows, self_rows  (nullable, uint8 per row of x / of self) a zero byte promises that the row is all zero: its
+ *                      entries are skipped without touching x (16-byte path; otherwise ignored).  The backward of the
+ *                      LAST aggregation layer: the loss's gradient reaches <= 3B of the N rows, so all but a fraction
+ *                      of a percent of the transpose SpMM's gathers would fetch zeros.                          */
 int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                            const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                            const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                            const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src, float *copy_dst,
-                           int64_t ld_copy_dst, float *rowmax_out, const int32_t *long_rows, int32_t n_long, int32_t long_thresh,
-                           void *stream);
+                           int64_t ld_copy_dst, float *rowmax_out, const uint8_t *x_rows, const uint8_t *self_rows,
+                           const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
 
 /* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
  * layer only needs the rows its consumers read.  lkg_csr_extract_rows copies the entries of the (sorted,
@@ -231,7 +235,7 @@ int lkg_scatter_add_rows_f32(int64_t n, int32_t d, const float *src, int64_t lds
                              const int32_t *perm, float *dst, int64_t ldd, void *stream);
 /* dst[idx[i],:] = value (dst nullable) and flags[idx[i]] = (flag != 0) (flags nullable, uint8 per table row): marks or
  * resets the <= 3B rows a loss gradient touches in an N-row table that is otherwise kept all-zero between steps, so that
- * no N x C fill runs per step (ops._RowScratch).                                                   */
+ * no N x C fill runs per step (ops._RowScratch).  Negative ids are skipped (padding of de-duplicated lists).   */
 int lkg_fill_rows_f32(int64_t n, int32_t d, const int64_t *idx, float *dst, int64_t ldd, float value, uint8_t *flags,
                       int32_t flag, void *stream);
 /* Row-range forms for a table sharded by rows over the ranks of one node (literalkg_amd/distributed.py): this rank
@@ -338,14 +342,15 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
  * the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32), for free.
  * g_yn_rows (nullable, uint8[n]): g_yn is known to be zero outside the rows whose byte is non-zero (the loss's
  * row-sparse gradient, lkg_fill_rows_f32) -- those rows skip the g_yn / y reads, and with g_y == NULL the whole
- * row (g_z = 0, no z read either).                                                              */
+ * row (g_z = 0, no z read either).  sparse_out != 0 (needs g_yn_rows, g_y == NULL, g_z_rowmax == NULL): g_z is a
+ * table the caller keeps all-zero outside the flagged rows, so the zero rows are not written either.        */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
                               float drop_p, uint64_t seed, float *g_z_rowmax, const uint8_t *g_yn_rows,
-                              void *stream);
+                              int32_t sparse_out, void *stream);
 
 /* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
  *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)

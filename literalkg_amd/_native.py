@@ -24,7 +24,7 @@ PROTOTYPES = {
     "lkg_laplacian_f32": [i64, i64, i64, vp, vp, vp, vp, i32, vp],
     "lkg_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp],
     "lkg_spmm_csr_fused_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp,
-                               i32, i32, vp],
+                               vp, vp, i32, i32, vp],
     "lkg_csr_extract_rows": [i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_spmm_csr_scatter_bwd_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp],
     "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, vp, vp,
@@ -50,7 +50,7 @@ PROTOTYPES = {
     "lkg_expand_groups_i32": [i64, i32, i32, vp, vp, vp, vp, vp],
     "lkg_act_layernorm_fwd_f32": [i64, i32, vp, i64, f32, vp, vp, f32, vp, i64, vp, i64, f32, vp, vp, f32, u64, vp],
     "lkg_act_layernorm_bwd_f32": [i64, i32, vp, i64, f32, vp, vp, i64, vp, vp, vp, i64, vp, i64, f32, vp, i64, vp,
-                                  vp, f32, u64, vp, vp, vp],
+                                  vp, f32, u64, vp, vp, i32, vp],
     "lkg_dot_score_fwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_dot_score_bwd_f32": [i64, i32, vp, i64, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp],
     "lkg_relu_batchnorm_fwd_f32": [i64, i32, vp, i64, vp, vp, f32, i32, f32, vp, vp, vp, i64, vp, vp, vp],

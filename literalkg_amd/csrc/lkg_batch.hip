@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(long n, int d, const lon
     const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const long r = idx[i];
+    if (r < 0) return;                 // (padding of a de-duplicated id list)
     if (dst)
         for (int c = lane; c < d; c += 64) dst[r * ldd + c] = value;
     if (flags && lane == 0) flags[r] = flag;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta,
                                                           float drop_p, unsigned long long seed,
                                                           float *__restrict__ gz_rowmax,
-                                                          const unsigned char *__restrict__ gyn_rows) {
+                                                          const unsigned char *__restrict__ gyn_rows, int sparse_out) {
     constexpr int K = CPL * W;
     __shared__ float red_g[3][K][64], red_b[3][K][64];
     const int lane = threadIdx.x & 63;
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
         RowRegs<W, CPL> zz, G, yy;
         const bool has_gyn = g_yn && (!gyn_rows || gyn_rows[row]);   // wave-uniform
         if (!g_y && !has_gyn) {   // no gradient reaches this row: g_z = 0, nothing to read or to add to g_gamma / g_beta
+            if (sparse_out) continue;     // (g_z is a table kept all-zero outside the flagged rows: nothing to write either)
             zz.load(z, 0, lane);   // zeros
             zz.store(g_z + row * ldgz, d, lane);
             if (gz_rowmax && lane == 0) gz_rowmax[row] = 0.f;
@@ -400,7 +401,9 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
                                          float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax,
-                                         const uint8_t *g_yn_rows, void *stream) {
+                                         const uint8_t *g_yn_rows, int32_t sparse_out, void *stream) {
+    LKG_REQUIRE(!sparse_out || (g_yn_rows && g_yn && !g_y && !g_z_rowmax),
+                "lkg_act_layernorm_bwd_f32: sparse_out needs row flags, no g_y and no row maxima");
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
@@ -415,7 +418,7 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
     const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 1024));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
-                     (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr);
+                     (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr, sparse_out);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
     return LKG_OK;
 }

@@ -12,6 +12,7 @@
 //     with xor-shuffles at the end, so every lane always carries a 16-byte load;
 //   * U edges are kept in flight per sub-group (unrolled, loads issued before the FMAs).
 #include <algorithm>
+#include <type_traits>
 
 #include "lkg_common.h"
 
@@ -111,6 +112,66 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
     }
 }
 
+// The same over a ROW-SPARSE x: xflags[c] == 0 promises that row c of x is all zero, and such entries are skipped
+// without touching x (the backward of the LAST aggregation layer: the loss's gradient reaches <= 3B of the N rows, so
+// all but a fraction of a percent of the transpose SpMM's gathers would fetch zeros).  Per 64-entry chunk: one coalesced
+// (col) load, one byte gather of the flags, a ballot; only chunks with a flagged entry load their values and gather
+// (64 / LPE flagged entries at a time, one per sub-group).  Four chunks are in flight so that the dependent col -> flag
+// round trips of a long row overlap.
+template <typename V, int LPE, int CPL, bool FULL>
+__device__ __forceinline__ void accumulate_entries_flagged(V (&acc)[CPL], int start, int end, int wave_i, int n_waves,
+                                                           int lane, int nchunk, const int *__restrict__ col,
+                                                           const float *__restrict__ val, const float *__restrict__ x,
+                                                           long ldx, const unsigned char *__restrict__ xflags) {
+    using ops = vec_ops<V>;
+    constexpr int EPW = 64 / LPE, G = 4;
+    const int sub = lane / LPE;
+    const int sl = lane % LPE;
+    for (int base0 = start + 64 * wave_i; base0 < end; base0 += 64 * n_waves * G) {
+        int c[G];
+        unsigned long long live[G];
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            const int j = base0 + 64 * n_waves * gq + lane;
+            c[gq] = col[min(j, end - 1)];
+        }
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            const int j = base0 + 64 * n_waves * gq + lane;
+            live[gq] = __ballot(j < end && xflags[c[gq]] != 0);
+        }
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            unsigned long long m = live[gq];
+            if (m == 0) continue;                                  // (wave-uniform)
+            const int j = base0 + 64 * n_waves * gq + lane;
+            const float v = val[min(j, end - 1)];
+            while (m) {
+                int cc = __builtin_amdgcn_readlane(c[gq], __builtin_ctzll(m));   // (a sub-group without an entry re-reads a live one, weight 0)
+                float vv = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPW; ++e) {                    // sub-group e takes the e-th flagged entry still pending
+                    const bool have = m != 0;
+                    const int b = have ? __builtin_ctzll(m) : 0;
+                    const int ce = __builtin_amdgcn_readlane(c[gq], b);
+                    const float ve = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
+                    if (sub == e) {
+                        cc = have ? ce : cc;
+                        vv = have ? ve : 0.f;
+                    }
+                    m &= m - 1;
+                }
+                const V *src = reinterpret_cast<const V *>(x + (long)cc * ldx);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    const int chunk = sl + i * LPE;
+                    ops::fma(acc[i], vv, FULL ? src[chunk] : src[min(chunk, nchunk - 1)]);
+                }
+            }
+        }
+    }
+}
+
 // Optional row-wise extras of the epilogue (lkg_spmm_csr_fused_f32): a second addend and a row copy riding along.
 struct SpmmExtra {
     const float *add2;       // out[i,:] += add2[i,:]
@@ -121,6 +182,8 @@ struct SpmmExtra {
     float *copy_dst;
     long ld_copy_dst;
     int *rowmax;             // rowmax[i] = max |out[i,:]| as the int bits of a non-negative float (atomicMax over the slabs)
+    const unsigned char *x_rows;      // nullable: rows of x that may be non-zero (accumulate_entries_flagged)
+    const unsigned char *self_rows;   // nullable: the same promise for `self`
     __device__ __forceinline__ const float *add2_row(long row) const {
         return add2 && (!add2_rows || add2_rows[row]) ? add2 + row * ld_add2 : nullptr;
     }
@@ -142,7 +205,7 @@ struct SpmmExtra {
 //                          fixed order (deterministic, no atomics).  They are dispatched first, so the longest
 //                          rows of a skewed graph overlap the bulk instead of being the tail of the launch.
 //   blocks [n_long, ...) : four ordinary rows, one wave each (rows over the threshold are skipped here).
-template <typename V, int LPE, int CPL, int U, bool FULL>
+template <typename V, int LPE, int CPL, int U, bool FULL, bool XF>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
                                                         const int *__restrict__ rowptr,
                                                         const int *__restrict__ col,
@@ -178,8 +241,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     V acc[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
-    accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val, x,
-                                             ldx);
+    if constexpr (XF)
+        accumulate_entries_flagged<V, LPE, CPL, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val,
+                                                      x, ldx, ex.x_rows);
+    else
+        accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val, x,
+                                                 ldx);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) reduce_subgroups<V, LPE>(acc[i]);
     if (team) {
@@ -199,7 +266,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     float rmax = 0.f;
     if (lane < LPE) {
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
-        const V *own = self ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
+        const V *own = self && (!ex.self_rows || ex.self_rows[row]) ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
         const V *own2 = reinterpret_cast<const V *>(ex.add2_row(row));
         const V *csrc = ex.copy_dst ? reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src) : nullptr;
         V *cdst = ex.copy_dst ? reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst) : nullptr;
@@ -350,7 +417,16 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
     const int64_t blocks = (n_rows + 3) / 4 + n_long;
     LKG_REQUIRE(blocks * n_slabs * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)",
                 (long long)(blocks * n_slabs));
-    hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0, s,
+    if constexpr (std::is_same<V, float4>::value) {
+        if (ex.x_rows) {
+            hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL, true>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0,
+                               s, (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self,
+                               (long)ld_self, long_rows, n_long, long_thresh, (int)blocks, slab_cols, ex);
+            LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
+            return LKG_OK;
+        }
+    }
+    hipLaunchKernelGGL((spmm_csr_kernel<V, LPE, CPL, U, FULL, false>), dim3((unsigned)(blocks * n_slabs)), dim3(256), 0, s,
                        (int)n_rows, nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self,
                        long_rows, n_long, long_thresh, (int)blocks, slab_cols, ex);
     LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
@@ -387,8 +463,9 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                                       const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                                       const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                                       const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src,
-                                      float *copy_dst, int64_t ld_copy_dst, float *rowmax_out, const int32_t *long_rows,
-                                      int32_t n_long, int32_t long_thresh, void *stream) {
+                                      float *copy_dst, int64_t ld_copy_dst, float *rowmax_out, const uint8_t *x_rows,
+                                      const uint8_t *self_rows, const int32_t *long_rows, int32_t n_long,
+                                      int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -412,7 +489,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         return LKG_ERR_HIP;
     }
     const SpmmExtra ex{add2, (long)ld_add2, add2 ? add2_rows : nullptr, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
-                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out)};
+                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr};
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
     // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
@@ -430,7 +507,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr,
                             copy_dst ? copy_src + c0 : nullptr,
                             (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst,
-                            reinterpret_cast<int *>(rowmax_out)};
+                            reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
                                         self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
@@ -445,7 +522,7 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                 const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                                 int32_t long_thresh, void *stream) {
     return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr,
-                                  nullptr, 0, nullptr, 0, nullptr, long_rows, n_long, long_thresh, stream);
+                                  nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, long_rows, n_long, long_thresh, stream);
 }
 
 // dst[i] = src[perm[i]]

@@ -98,12 +98,14 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
              add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
              copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-             rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+             rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None,
+             x_rows: Optional[torch.Tensor] = None, self_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
-    epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own).  add2_rows
-    (uint8 per row): add2 is zero outside the flagged rows and is read there only."""
+    epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own).  add2_rows /
+    x_rows / self_rows (uint8 per row of add2 / x / add_self): the operand is zero outside the flagged rows and is read
+    there only (x_rows is indexed like x: by col - x_row_offset)."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -120,8 +122,9 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
            x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
            _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
            N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
-           N.ptr(rowmax), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
-           _stream())
+           N.ptr(rowmax), (x_rows.data_ptr() - x_row_offset) if x_rows is not None else None,
+           N.ptr(self_rows if add_self is not None else None), N.ptr(long_rows),
+           0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
     return out
 
 
@@ -223,19 +226,49 @@ def tagged_rowmax(t: torch.Tensor) -> Optional[torch.Tensor]:
     return tag[1]
 
 
-def tag_rows(t: torch.Tensor, flags: Optional[torch.Tensor]) -> torch.Tensor:
-    """Remember on the tensor OBJECT that t is zero outside the rows whose flag byte is set (a loss's row-sparse
-    gradient).  t itself stays dense and correct: a consumer that does not look at the tag just reads the zeros."""
-    if flags is not None:
-        t._lkg_rows = (t._version, flags)
+class RowSet:
+    """The rows of an N-row table that may be non-zero: the <= 3B rows a loss's gradient reaches.  ``flags`` (uint8 per
+    row) is what the kernels look at; ``compact_ids()`` lists every such row exactly once (no host sync: the list has the
+    length of the id lists it came from, duplicates replaced by -1, which the row kernels skip)."""
+
+    def __init__(self, flags: torch.Tensor, id_lists: Sequence[torch.Tensor]):
+        self.flags = flags
+        self.id_lists = [i.reshape(-1) for i in id_lists]
+        self.n_max = sum(i.numel() for i in self.id_lists)
+        self._ids = None
+
+    def compact_ids(self) -> torch.Tensor:
+        if self._ids is None:       # (index bookkeeping over <= 3B ids)
+            s_ = torch.sort(torch.cat(self.id_lists)).values
+            dup = torch.zeros_like(s_, dtype=torch.bool)
+            dup[1:] = s_[1:] == s_[:-1]
+            self._ids = torch.where(dup, torch.full_like(s_, -1), s_)
+        return self._ids
+
+
+def tag_rows(t: torch.Tensor, rows: Optional[RowSet]) -> torch.Tensor:
+    """Remember on the tensor OBJECT that t is zero outside ``rows`` (a loss's row-sparse gradient and what the last
+    layer's backward derives from it).  t itself stays dense and correct: a consumer that does not look at the tag just
+    reads the zeros."""
+    if rows is not None:
+        t._lkg_rows = (t._version, rows)
     return t
 
 
-def tagged_rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+def tagged_rows(t: Optional[torch.Tensor]) -> Optional[RowSet]:
     tag = getattr(t, "_lkg_rows", None) if t is not None else None
-    if tag is None or tag[0] != t._version or tag[1].shape[0] != t.shape[0] or tag[1].device != t.device:
+    if tag is None or tag[0] != t._version or tag[1].flags.shape[0] != t.shape[0] or tag[1].flags.device != t.device:
         return None
     return tag[1]
+
+
+def _flags(rows: Optional[RowSet]) -> Optional[torch.Tensor]:
+    return rows.flags if rows is not None else None
+
+
+def rows_worth_compacting(rows: Optional[RowSet], n: int) -> bool:
+    """Is the row set small enough that work on the listed rows beats a pass over all n?"""
+    return rows is not None and n >= TALL_MIN_ROWS and rows.n_max * 8 <= n
 
 
 def _storage_users(t: torch.Tensor) -> int:
@@ -245,26 +278,28 @@ def _storage_users(t: torch.Tensor) -> int:
 class _RowScratch:
     """The gradient a loss returns for the N x C entity table touches <= 3B of its rows, yet autograd wants it dense:
     an N x C zero fill per step (2 GB at 1 M x 512) plus the consumers' reads of those zeros.  Here ONE table per shape
-    is kept all-zero BETWEEN steps: a backward resets the rows the previous one touched (lkg_fill_rows_f32), scatters
-    its own, and tags the result with a per-row flag array so that the aware consumers (act_ln backward, the first
-    layer's transpose SpMM) skip the zero rows.  Only for tables whose gradient is consumed inside the backward pass by
-    this package's own Functions (the caller says so: ``sparse_rows``); as a second guard the table is re-used only when
-    no view of it is alive any more (storage use count back at its baseline), otherwise a fresh one replaces it."""
+    (and purpose) is kept all-zero BETWEEN steps: a backward resets the rows the previous one touched
+    (lkg_fill_rows_f32), scatters its own, and tags the result with the RowSet so that the aware consumers skip the zero
+    rows: act_ln backward, the transpose SpMM, and -- for the LAST layer, whose only gradient is that table's slice --
+    the Linear's whole backward, which then works on the listed rows alone.  Only for tables whose gradient is consumed
+    inside the backward pass by this package's own Functions (the caller says so: ``sparse_rows``); as a second guard a
+    table is re-used only when no view of it is alive any more (storage use count back at its baseline), otherwise a
+    fresh one replaces it."""
 
     _tables: dict = {}
 
-    def __init__(self, like: torch.Tensor):
-        self.buf = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
-        self.flags = torch.zeros(like.shape[0], dtype=torch.uint8, device=like.device)
+    def __init__(self, shape, device, with_flags: bool):
+        self.buf = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        self.flags = torch.zeros(shape[0], dtype=torch.uint8, device=device) if with_flags else None
         self.users = _storage_users(self.buf)
         self.dirty: list = []
 
     @classmethod
-    def acquire(cls, like: torch.Tensor) -> "_RowScratch":
-        key = (like.device, like.shape[0], like.shape[1])
+    def acquire(cls, n: int, c: int, device, pool: str = "loss") -> "_RowScratch":
+        key = (device, n, c, pool)
         ent = cls._tables.get(key)
         if ent is None or _storage_users(ent.buf) != ent.users:
-            ent = cls._tables[key] = _RowScratch(like)
+            ent = cls._tables[key] = _RowScratch((n, c), device, pool == "loss")
         for ids in ent.dirty:
             N.call("lkg_fill_rows_f32", ids.numel(), ent.buf.shape[1], N.ptr(ids), N.ptr(ent.buf), _ld(ent.buf), 0.0,
                    N.ptr(ent.flags), 0, _stream())
@@ -273,21 +308,38 @@ class _RowScratch:
 
     def mark(self, *id_lists: torch.Tensor):
         for ids in id_lists:
-            N.call("lkg_fill_rows_f32", ids.numel(), 0, N.ptr(ids), None, 0, 0.0, N.ptr(self.flags), 1, _stream())
+            if self.flags is not None:
+                N.call("lkg_fill_rows_f32", ids.numel(), 0, N.ptr(ids), None, 0, 0.0, N.ptr(self.flags), 1, _stream())
             self.dirty.append(ids)
 
-    def table(self) -> torch.Tensor:
+    def table(self, rows: RowSet) -> torch.Tensor:
         """A fresh view per hand-out: while autograd (or anybody) holds it, the storage count shows it."""
-        return tag_rows(self.buf.view(self.buf.shape), self.flags)
+        return tag_rows(self.buf.view(self.buf.shape), rows)
 
 
 def _loss_grad_table(emb: torch.Tensor, sparse_rows: bool, *id_lists: torch.Tensor) -> torch.Tensor:
     """The all-zero N x C table a loss backward scatters its rows ``id_lists`` (int64, contiguous) into."""
     if not sparse_rows:
         return torch.zeros_like(emb, memory_format=torch.contiguous_format)
-    ent = _RowScratch.acquire(emb)
+    ent = _RowScratch.acquire(emb.shape[0], emb.shape[1], emb.device)
     ent.mark(*id_lists)
-    return ent.table()
+    return ent.table(RowSet(ent.flags, id_lists))
+
+
+def gather_rows_range(table: torch.Tensor, ids: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    """out[i, :] = table[ids[i] - lo, :] for ids in [lo, hi), zeros for the others (-1 padding, rows of other shards)."""
+    table = _f32_rows(table)
+    out = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    N.call("lkg_gather_rows_range_f32", ids.numel(), table.shape[1], N.ptr(table), _ld(table), N.ptr(ids), int(lo), int(hi),
+           N.ptr(out), table.shape[1], _stream())
+    return out
+
+
+def zero_table_for(rows: RowSet, n: int, c: int, device, pool: str) -> torch.Tensor:
+    """An n x c table that is zero everywhere and that the caller fills in ``rows`` only (tagged accordingly)."""
+    ent = _RowScratch.acquire(n, c, device, pool)
+    ent.mark(rows.compact_ids())
+    return ent.table(rows)
 
 
 def row_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
@@ -438,9 +490,10 @@ class _Aggregate(Function):
         g = ctx.g
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
+        rows = _flags(tagged_rows(grad))      # the last layer's gradient: all but <= 3B rows are zero and are not gathered
         grad = _f32_rows(grad)
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True),
-                        add_self=grad if ctx.plus_self else None), None, None, None, None
+                        add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows), None, None, None, None
 
 
 def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor,
@@ -477,10 +530,11 @@ class _AggregateKeep(Function):
             return g_kept, None, None, None, None, None
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
+        rows = _flags(tagged_rows(g_side))
         g_side = _f32_rows(g_side)
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
                         add_self=g_side if ctx.plus_self else None, add2=g_kept,
-                        add2_rows=tagged_rows(g_kept)), None, None, None, None, None
+                        add2_rows=_flags(tagged_rows(g_kept)), x_rows=rows, self_rows=rows), None, None, None, None, None
 
 
 def aggregate_keep(ego, g: KGStructure, val, val_t, plus_self: bool = False, keep_dst: Optional[torch.Tensor] = None):
@@ -514,6 +568,9 @@ class _MultiLinear(Function):
         n = ctx.n_terms
         saved = ctx.saved_tensors
         xs, ws = saved[:n], saved[n:]
+        rows = tagged_rows(gy)
+        if rows_worth_compacting(rows, gy.shape[0]):
+            return _MultiLinear._backward_on_rows(ctx, gy, rows, xs, ws)
         gy = _f32_rows(gy)
         gxs = []
         rm = None
@@ -526,6 +583,30 @@ class _MultiLinear(Function):
             else:
                 gxs.append(gemm(gy, ws[i]))
         gws, gb = weight_grads(gy, xs, ctx.needs_input_grad[2 + n:2 + 2 * n], ctx.has_bias and ctx.needs_input_grad[0])
+        return (gb, None, *gxs, *gws)
+
+    @staticmethod
+    def _backward_on_rows(ctx, gy, rows: RowSet, xs, ws):
+        """gy is zero outside ``rows`` (the last layer under a loss on <= 3B rows): every product of the backward is the
+        same product over the listed rows -- gathered once, a few thousand of them -- and the data gradient is their
+        scatter into a table that is kept all-zero elsewhere (and tells ITS consumer which rows those are)."""
+        n = ctx.n_terms
+        ids = rows.compact_ids()                                   # every row once, -1 padding (gathers as zeros)
+        n_rows = gy.shape[0]
+        gc = gather_rows_range(gy, ids, 0, n_rows)
+        gb = colsum(gc) if (ctx.has_bias and ctx.needs_input_grad[0]) else None
+        gxs, gws = [], []
+        for i in range(n):
+            if not ctx.needs_input_grad[2 + i]:
+                gxs.append(None)
+                continue
+            gx = zero_table_for(rows, n_rows, ws[i].shape[1], gy.device, f"g_x{i}")
+            N.call("lkg_scatter_add_rows_range_f32", ids.numel(), ws[i].shape[1], N.ptr(gemm(gc, ws[i])), ws[i].shape[1],
+                   N.ptr(ids), 0, n_rows, N.ptr(gx), _ld(gx), _stream())
+            gxs.append(gx)
+        for i in range(n):
+            gws.append(gemm(gc, gather_rows_range(xs[i], ids, 0, n_rows), trans_a=True)
+                       if ctx.needs_input_grad[2 + n + i] else None)
         return (gb, None, *gxs, *gws)
 
 
@@ -668,17 +749,23 @@ class _ActLayerNorm(Function):
         none = (None,) * 10
         if gy is None and gyn is None:
             return none
-        gyn_rows = tagged_rows(gyn)      # a loss's row-sparse gradient: the kernel skips the zero rows
+        rows = tagged_rows(gyn)          # a loss's row-sparse gradient: the kernel skips the zero rows
         gy = _f32_rows(gy) if gy is not None else None
         gyn = _f32_rows(gyn) if gyn is not None else None
-        gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
         gg = torch.zeros(d, dtype=torch.float32, device=z.device)
         gb = torch.zeros(d, dtype=torch.float32, device=z.device)
-        rm = torch.empty(n, dtype=torch.float32, device=z.device) if _wants_rowmax(n) else None    # for the Linear's data gradient
+        # the LAST layer (no g_y): g_z is zero outside those rows too -- it goes into a table kept all-zero between steps
+        # (only the listed rows are written) and carries the row set on to the Linear's backward and the transpose SpMM
+        sparse_out = gy is None and rows_worth_compacting(rows, n)
+        if sparse_out:
+            gz, rm = zero_table_for(rows, n, d, z.device, "g_z"), None
+        else:
+            gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
+            rm = torch.empty(n, dtype=torch.float32, device=z.device) if _wants_rowmax(n) else None   # for the Linear's data gradient
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               float(drop_p), int(seed), N.ptr(rm), N.ptr(gyn_rows), _stream())
+               float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows)), int(sparse_out), _stream())
         return (tag_rowmax(gz, rm), gg, gb) + none[3:]
 
 

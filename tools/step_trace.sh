@@ -3,7 +3,7 @@
 cfg=$1; out=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 tools/step_profile.py --config $cfg --iters 10 > $out/step.log 2> $out/step.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 tools/step_profile.py --config $cfg --iters ${ITERS:-10} $EXTRA > $out/step.log 2> $out/step.err || exit 1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$out/stats/**/*kernel_stats.csv", recursive=True)[0]
