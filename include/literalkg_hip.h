@@ -343,14 +343,16 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
  * g_yn_rows (nullable, uint8[n]): g_yn is known to be zero outside the rows whose byte is non-zero (the loss's
  * row-sparse gradient, lkg_fill_rows_f32) -- those rows skip the g_yn / y reads, and with g_y == NULL the whole
  * row (g_z = 0, no z read either).  sparse_out != 0 (needs g_yn_rows, g_y == NULL, g_z_rowmax == NULL): g_z is a
- * table the caller keeps all-zero outside the flagged rows, so the zero rows are not written either.        */
+ * table the caller keeps all-zero outside the flagged rows, so the zero rows are not written either; row_ids
+ * (nullable, int64[n_row_ids], with sparse_out) then lists the flagged rows (negative entries = padding) and only
+ * those are visited: the launch is over the <= 3B rows the loss reaches instead of N.                        */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,
                               float drop_p, uint64_t seed, float *g_z_rowmax, const uint8_t *g_yn_rows,
-                              int32_t sparse_out, void *stream);
+                              int32_t sparse_out, const int64_t *row_ids, int64_t n_row_ids, void *stream);
 
 /* K6  literal-gate blend (gate.py:24-26, 47-49) on the two pre-activations
  *   out = (1 - sigmoid(zpre)) * x + sigmoid(zpre) * tanh(gpre)

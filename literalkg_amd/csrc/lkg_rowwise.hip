@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta,
                                                           float drop_p, unsigned long long seed,
                                                           float *__restrict__ gz_rowmax,
-                                                          const unsigned char *__restrict__ gyn_rows, int sparse_out) {
+                                                          const unsigned char *__restrict__ gyn_rows, int sparse_out,
+                                                          const long *__restrict__ row_ids, long n_row_ids) {
     constexpr int K = CPL * W;
     __shared__ float red_g[3][K][64], red_b[3][K][64];
     const int lane = threadIdx.x & 63;
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
 #pragma unroll
     for (int k = 0; k < K; ++k) acc_g[k] = acc_b[k] = 0.f;
 
-    for (long row = wave; row < n; row += nwaves) {
+    const long n_iter = row_ids ? n_row_ids : n;     // with a row list: only the listed rows (negative entries: padding)
+    for (long it = wave; it < n_iter; it += nwaves) {
+        const long row = row_ids ? row_ids[it] : it;
+        if (row < 0) continue;
         RowRegs<W, CPL> zz, G, yy;
         const bool has_gyn = g_yn && (!gyn_rows || gyn_rows[row]);   // wave-uniform
         if (!g_y && !has_gyn) {   // no gradient reaches this row: g_z = 0, nothing to read or to add to g_gamma / g_beta
@@ -401,9 +405,11 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
                                          float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax,
-                                         const uint8_t *g_yn_rows, int32_t sparse_out, void *stream) {
+                                         const uint8_t *g_yn_rows, int32_t sparse_out, const int64_t *row_ids,
+                                         int64_t n_row_ids, void *stream) {
     LKG_REQUIRE(!sparse_out || (g_yn_rows && g_yn && !g_y && !g_z_rowmax),
                 "lkg_act_layernorm_bwd_f32: sparse_out needs row flags, no g_y and no row maxima");
+    LKG_REQUIRE(!row_ids || (sparse_out && n_row_ids >= 0), "lkg_act_layernorm_bwd_f32: a row list needs sparse_out");
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
@@ -415,10 +421,13 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                      (!g_yn || (ldgyn % 4 == 0 && ldy % 4 == 0)) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
                      lkg_aligned16(gamma) && (!g_y || lkg_aligned16(g_y)) &&
                      (!g_yn || (lkg_aligned16(g_yn) && lkg_aligned16(y)));
-    const dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, 1024));
+    const int64_t n_work = row_ids ? n_row_ids : n;
+    if (n_work == 0) return LKG_OK;
+    const dim3 grid((unsigned)std::min<int64_t>((n_work + 3) / 4, 1024));
     LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
-                     (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr, sparse_out);
+                     (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr, sparse_out,
+                     (const long *)row_ids, (long)n_row_ids);
     LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
     return LKG_OK;
 }

@@ -496,7 +496,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     // flight and a 128-column slab of the source table is 2-4x more likely to be served from the 256 MiB
     // Infinity Cache -- at the price of re-reading the (col, val) stream once per slab (+8 B per entry per slab).
     // The scalar (unaligned) path keeps up to 256 columns per launch.
-    const int block_cols = vec ? 128 : 256;
+    // (over a row-sparse x almost nothing is gathered: one pass over the entry stream per 256 columns, not per 128)
+    const int block_cols = (vec && !x_rows) ? 128 : 256;
     if (d > block_cols && d % block_cols == 0)     // equal slabs: one launch, slab-major workgroup order
         return vec ? dispatch<float4>(n_rows, block_cols / 4, rowptr, col, val, x, ldx, out, ldo, self, ld_self,
                                       long_rows, n_long, long_thresh, d / block_cols, block_cols, ex, s)

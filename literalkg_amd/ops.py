@@ -757,6 +757,7 @@ class _ActLayerNorm(Function):
         # the LAST layer (no g_y): g_z is zero outside those rows too -- it goes into a table kept all-zero between steps
         # (only the listed rows are written) and carries the row set on to the Linear's backward and the transpose SpMM
         sparse_out = gy is None and rows_worth_compacting(rows, n)
+        ids = rows.compact_ids() if sparse_out else None
         if sparse_out:
             gz, rm = zero_table_for(rows, n, d, z.device, "g_z"), None
         else:
@@ -765,7 +766,8 @@ class _ActLayerNorm(Function):
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows)), int(sparse_out), _stream())
+               float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows)), int(sparse_out),
+               N.ptr(ids) if sparse_out else None, ids.numel() if sparse_out else 0, _stream())
         return (tag_rowmax(gz, rm), gg, gb) + none[3:]
 
 
