@@ -263,14 +263,16 @@ int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t seed, const
                         int64_t *out_neg_t, void *stream);
 
 /* Grouped fp32 MFMA GEMM over segments seg[g]..seg[g+1] (device int32[n_groups+1], no host sync):
- *  mode 1 (rows): C[seg rows,:] = alpha * A[seg rows,:] opB(B + g*stride_b) + beta*C   (A row-major)
- *                 max_seg_len bounds the longest segment (e.g. the batch size).
+ *  mode 1 (rows): C[seg rows,:] = alpha * A[seg rows,:] opB(B + (g % b_period)*stride_b) + beta*C   (A row-major)
+ *                 max_seg_len bounds the longest segment (e.g. the batch size); b_period (0: = n_groups) lets several
+ *                 row ranges share a B block: the head, positive-tail and negative-tail rows of a TransR batch, each
+ *                 sorted by relation, are 3 R groups over the R matrices of gat_trans_M -- one launch.
  *  mode 2 (k)   : (C + g*stride_c)[m,n] = alpha * sum_{k in seg} A[k,m] B[k,n] + beta*C
  *                 (A given transposed, trans_a = 1; B k-major, trans_b = 0): g_W[r] = X_r^T G_r.   */
 int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int64_t max_seg_len,
                          int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                          const float *a, int64_t lda, const float *b, int64_t ldb, int64_t stride_b,
-                         float beta, float *c, int64_t ldc, int64_t stride_c, void *stream);
+                         int32_t b_period, float beta, float *c, int64_t ldc, int64_t stride_c, void *stream);
 
 /* f1  fine-tuning head (model.py:316-348): dot-product BPR on table rows
  *   pos_b = <e_h, e_p>, neg_b = <e_h, e_n>, reg_b = (|e_h|^2 + |e_p|^2 + |e_n|^2)/2,

@@ -41,7 +41,7 @@ PROTOTYPES = {
     "lkg_gather_rows_range_f32": [i64, i32, vp, i64, vp, i64, i64, vp, i64, vp],
     "lkg_scatter_add_rows_range_f32": [i64, i32, vp, i64, vp, i64, i64, vp, i64, vp],
     "lkg_sample_kg_batch": [i64, i32, u64, vp, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp],
-    "lkg_grouped_gemm_f32": [i32, i32, vp, i64, i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, i64, f32, vp, i64,
+    "lkg_grouped_gemm_f32": [i32, i32, vp, i64, i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, i64, i32, f32, vp, i64,
                              i64, vp],
     "lkg_dense_score_fwd_f32": [i64, i32, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],
     "lkg_dense_score_bwd_f32": [i64, i32, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp, vp, vp, vp, i64, vp, i64,

@@ -26,7 +26,7 @@
 // range of tiles (n fastest): the tiles that share an A panel run on the same L2 (measured +1 %).
 //
 // Grouped forms (relation-grouped W_r GEMM, model.py:372/390-395 without materialising W_r[r]):
-//   rows mode : rows [seg[g], seg[g+1]) of A and C use B + g * stride_b     (projection, data gradient)
+//   rows mode : rows [seg[g], seg[g+1]) of A and C use B + (g % b_period) * stride_b     (projection, data gradient)
 //   k mode    : the reduction runs over rows [seg[g], seg[g+1]) of A^T and B, output C + g * stride_c
 //               (weight gradient  g_W[r] = X_r^T G_r)
 // Plain long-K / small-output products (nn.Linear weight gradients, K = n_entities) are split over K
@@ -59,6 +59,7 @@ struct GemmArgs {
     const float *bias;
     const int *seg;      // grouped forms: device int32[n_groups + 1]
     long stride_b, stride_c;
+    int b_period;        // rows mode: group z uses B block z % b_period (0: block z)
     int mode;            // 0 plain, 1 rows grouped, 2 k grouped
     int k_splits;        // plain mode only (atomic accumulation when > 1)
     int tiles_m, tiles_n;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (g.mode == 1) {
         m_lo = g.seg[z];
         m_hi = g.seg[z + 1];
-        B += (long)z * g.stride_b;
+        B += (long)(g.b_period > 0 ? z % g.b_period : z) * g.stride_b;
     } else if (g.mode == 2) {
         k_lo = g.seg[z];
         k_hi = g.seg[z + 1];
@@ -668,7 +669,8 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
 extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_t *seg, int64_t max_seg_len,
                                     int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                                     const float *a, int64_t lda, const float *b, int64_t ldb, int64_t stride_b,
-                                    float beta, float *c, int64_t ldc, int64_t stride_c, void *stream) {
+                                    int32_t b_period, float beta, float *c, int64_t ldc, int64_t stride_c,
+                                    void *stream) {
     LKG_REQUIRE(mode == 1 || mode == 2, "lkg_grouped_gemm_f32: mode must be 1 (rows) or 2 (k)");
     LKG_REQUIRE(n_groups >= 0 && n_groups <= 65535 && max_seg_len >= 0, "lkg_grouped_gemm_f32: bad group count");
     if (n_groups == 0 || n == 0) return LKG_OK;
@@ -678,6 +680,7 @@ extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_
     GemmArgs g{};
     g.alpha = alpha; g.beta = beta; g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.c = c; g.ldc = ldc;
     g.bias = nullptr; g.seg = seg; g.stride_b = stride_b; g.stride_c = stride_c; g.mode = mode; g.k_splits = 1;
+    g.b_period = mode == 1 ? b_period : 0;
     g.n = n;
     if (mode == 1) {
         g.m = max_seg_len;   // upper bound; the kernel reads the true range from seg

@@ -983,10 +983,10 @@ def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None, sparse_rows: bo
 
 
 # ----------------------------------------------------------------------------- K7+K8 TransR scoring
-def _grouped(mode, seg, max_len, a, b, out, m, n, k, trans_a, trans_b, beta, stride_b=0, stride_c=0):
+def _grouped(mode, seg, max_len, a, b, out, m, n, k, trans_a, trans_b, beta, stride_b=0, stride_c=0, b_period=0):
     N.call("lkg_grouped_gemm_f32", mode, seg.numel() - 1, N.ptr(seg), max_len, int(trans_a), int(trans_b), m, n, k,
-           1.0, N.ptr(a), _ld(a), N.ptr(b), b.stride(-2), stride_b, float(beta), N.ptr(out), out.stride(-2), stride_c,
-           _stream())
+           1.0, N.ptr(a), _ld(a), N.ptr(b), b.stride(-2), stride_b, int(b_period), float(beta), N.ptr(out),
+           out.stride(-2), stride_c, _stream())
 
 
 def is_grouped_batch(h, r, pos_t, group_size: int) -> bool:
@@ -1052,14 +1052,15 @@ class _TransRLoss(Function):
         for ids, pm, sg, off, rows in parts:
             N.call("lkg_gather_rows_f32", rows, c, N.ptr(emb), _ld(emb), N.ptr(ids), N.ptr(pm), N.ptr(x[off:]), c,
                    _stream())
-            _grouped(1, sg, rows, x[off:off + rows], trans_m, p[off:off + rows], 0, dout, c, False, False, 0.0,
-                     stride_b=c * dout)
+        # the three row blocks are each sorted by relation: 3 R row ranges over the R matrices, ONE grouped launch
+        seg_all = torch.cat([seg, seg[1:] + n_g, seg_n[1:] + 2 * n_g])
+        _grouped(1, seg_all, max(b, n_g), x, trans_m, p, 0, dout, c, False, False, 0.0, stride_b=c * dout, b_period=n_rel)
         buf = torch.empty((4, b), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         N.call("lkg_dense_score_fwd_f32", b, k, dout, N.ptr(p), N.ptr(p[n_g:]), N.ptr(p[2 * n_g:]), dout, N.ptr(relemb),
                _ld(relemb), N.ptr(rs), N.ptr(buf[0]), N.ptr(buf[1]), N.ptr(buf[2]), N.ptr(buf[3]), _stream())
         N.call("lkg_loss_reduce_f32", b, N.ptr(buf[3]), N.ptr(buf[2]), float(lam), N.ptr(loss), _stream())
-        ctx.save_for_backward(emb, relemb, trans_m, hg, pg, nt, rs, perm, seg, perm_n, seg_n, x, p, buf)
+        ctx.save_for_backward(emb, relemb, trans_m, hg, pg, nt, rs, perm, seg, perm_n, seg_n, x, p, buf, seg_all)
         ctx.lam, ctx.k = lam, k
         if keep is not None:   # scores back in the caller's triple order
             inv = torch.empty(b, dtype=torch.int64, device=dev)
@@ -1069,7 +1070,7 @@ class _TransRLoss(Function):
 
     @staticmethod
     def backward(ctx, gl):
-        emb, relemb, trans_m, hg, pg, nt, rs, perm, seg, perm_n, seg_n, x, p, buf = ctx.saved_tensors
+        emb, relemb, trans_m, hg, pg, nt, rs, perm, seg, perm_n, seg_n, x, p, buf, seg_all = ctx.saved_tensors
         n_rel, c, dout = trans_m.shape
         b, k = nt.numel(), ctx.k
         n_g = b // k
@@ -1082,15 +1083,15 @@ class _TransRLoss(Function):
                N.ptr(gp[n_g:]), N.ptr(gp[2 * n_g:]), dout, N.ptr(g_rel), _ld(g_rel), _stream())
         g_w = torch.empty_like(trans_m)
         g_emb = _loss_grad_table(emb, ctx.sparse_rows, hg, pg, nt)
-        gx = torch.empty((max(b, n_g), c), dtype=torch.float32, device=dev)
+        gx = torch.empty((2 * n_g + b, c), dtype=torch.float32, device=dev)
+        # g_X = G W_r^T for the three row blocks in one grouped launch, scattered back to the table rows below
+        _grouped(1, seg_all, max(b, n_g), gp, trans_m, gx, 0, c, dout, False, True, 0.0, stride_b=c * dout, b_period=n_rel)
         parts = ((hg, perm, seg, 0, n_g), (pg, perm, seg, n_g, n_g), (nt, perm_n, seg_n, 2 * n_g, b))
         for i, (ids, pm, sg, off, rows) in enumerate(parts):
             xi, gi = x[off:off + rows], gp[off:off + rows]
             # g_W[r] (+)= X_r^T G_r
             _grouped(2, sg, rows, xi, gi, g_w, c, dout, 0, True, False, 0.0 if i == 0 else 1.0, stride_c=c * dout)
-            # g_X = G W_r^T, scattered back to the table rows
-            _grouped(1, sg, rows, gi, trans_m, gx[:rows], 0, c, dout, False, True, 0.0, stride_b=c * dout)
-            N.call("lkg_scatter_add_rows_f32", rows, c, N.ptr(gx), c, N.ptr(ids), N.ptr(pm), N.ptr(g_emb),
+            N.call("lkg_scatter_add_rows_f32", rows, c, N.ptr(gx[off:]), c, N.ptr(ids), N.ptr(pm), N.ptr(g_emb),
                    _ld(g_emb), _stream())
         return g_emb, g_rel, g_w, None, None, None, None, None, None, None, None
 

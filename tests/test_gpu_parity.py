@@ -985,7 +985,7 @@ def test_device_entry_points_reject_bad_arguments(L, ops, gpu_device):
     with pytest.raises(N.LkgError, match="dropout probability"):
         ops.act_layernorm(x, torch.ones(8, device=gpu_device), torch.zeros(8, device=gpu_device), drop_p=1.5, seed=1)
     with pytest.raises(N.LkgError, match="mode must be"):
-        N.call("lkg_grouped_gemm_f32", 3, 1, N.ptr(rp), 4, 0, 0, 4, 8, 8, 1.0, N.ptr(x), 8, N.ptr(x), 8, 0, 0.0,
+        N.call("lkg_grouped_gemm_f32", 3, 1, N.ptr(rp), 4, 0, 0, 4, 8, 8, 1.0, N.ptr(x), 8, N.ptr(x), 8, 0, 0, 0.0,
                N.ptr(x), 8, 0, None)
     with pytest.raises(ValueError, match="inner dimensions"):
         ops.gemm(x, x)
