@@ -368,7 +368,8 @@ class ShardedLiteralKG(nn.Module):
         m = self.local
         k = int(m.pre_training_neg_rate)
         b = h.numel()
-        group = k if (m.scoring == "transr" and m.group_reuse and ops.is_grouped_batch(h, r, pos_t, k)) else 1
+        group = k if (m.scoring == "transr" and m.group_reuse and k >= m.group_reuse_min_rate
+                      and ops.is_grouped_batch(h, r, pos_t, k)) else 1
         # the batch's rows, once per group for (h, t+): positions into the gathered rows replace the entity ids
         hg, pg = h[::group], pos_t[::group]
         n_g = hg.numel()
