@@ -370,6 +370,18 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
                            int64_t ldgo, float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg,
                            float *g_zpre, int64_t ldgz, int32_t activated, float *g_pre_rowmax, void *stream);
 
+/* Weight-gradient product on the fp16 matrix cores (lkg_gemm_wgrad.hip):  C[m, n] = sum over the k rows of
+ * A[k, m] * B[k, n]  (both operands k-major: dW = dY^T X of nn.Linear with k = rows, model.py:93-149, gate.py:22-25),
+ * f32 in / f32 out, C overwritten.  a_colmax / b_colmax (device float[m] / float[n]): max |A[:, j]| / max |B[:, j]| --
+ * every column is scaled by the power of two that brings its maximum to [2^13, 2^14), split exactly into two fp16
+ * halves and multiplied with three fp16 MFMAs per product (f32-accurate normwise; lkg_gemm_f32 uses six bf16 MFMAs and
+ * needs no scales).  A bound that is too small by more than a factor 4 can overflow fp16: pass true maxima (emitted by
+ * the operand's producer -- lkg_gate_blend_bwd_f32, lkg_row_absmax_f32 -- or lkg_col_absmax_f32 for constant tables). */
+int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
+                       const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc, void *stream);
+/* out[c] = max_r |x[r,c]|  (out is overwritten)                                                     */
+int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
+
 /* out[c] = sum_r x[r,c]  (bias gradients of nn.Linear; out is overwritten)                       */
 int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 /* out_w[c, j] = sum_r x[r,c] * w[r,j] for a NARROW w (1 <= n_w <= 8 columns) and, when out_sum != NULL,

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "liblkg_hip.so")
 SOURCES = ["lkg_graph_host.cpp", "lkg_spmm.hip", "lkg_attention.hip", "lkg_score.hip", "lkg_rowwise.hip",
-           "lkg_gemm.hip", "lkg_batch.hip", "lkg_csr_device.hip", "lkg_gemm_tall.hip"]
+           "lkg_gemm.hip", "lkg_batch.hip", "lkg_csr_device.hip", "lkg_gemm_tall.hip", "lkg_gemm_wgrad.hip"]
 
 
 def _stale():

@@ -1,0 +1,295 @@
+// Weight-gradient product on the fp16 matrix cores ("f16 x 2", the k-major twin of lkg_gemm_tall.hip):
+//
+//   C[m, n] = sum over the k rows of  A[k, m] * B[k, n]          (A = dY or [g_gpre | g_zpre], B = the layer input / a
+//                                                                 literal panel; k = entities, millions; m, n <= ~1000)
+//
+// Both operands arrive k-major (a thread sees 8 consecutive COLUMNS of one k), so the scale that keeps the fp16 split
+// exact has to be per COLUMN of each operand: column j is multiplied by the power of two that puts its largest
+// magnitude into [2^13, 2^14), every element is split into hi = fp16(a') (round toward zero) and
+// mid = fp16((a' - hi) * 2^11), and  a'.b' = hi_a hi_b + hs_a mid_b + mid_a hs_b  with hs = hi * 2^-11 (an exact exponent
+// shift): THREE v_mfma_f32_32x32x16_f16 per 16 k and 32 x 32 tile into ONE f32 accumulator, unscaled by an exact ldexp
+// by -(e_m + e_n) in the epilogue -- against the six bf16 MFMAs (and the three-plane split) of lkg_gemm_f32's engine 2.
+// Elements down to 2^-16 of their column's maximum carry the full 22 bits, smaller ones lose bits of the two cross
+// terms only (their absolute error stays below 2^-35 of the column maximum times |b|): normwise the result is as
+// accurate as an f32 GEMM's (tests against f64).  The column maxima are inputs: the producers of the operands emit
+// them while they write (lkg_gate_blend_bwd_f32, lkg_row_absmax_f32's column output) or they are computed once for
+// constant tables (lkg_col_absmax_f32); without them the caller stays on the bf16 x 3 engine.
+//
+// Structure = lkg_gemm.hip's engine 2: 128 x 128 tile, 4 waves of 64 x 64, 16-k steps, planes [16 k][128 cols] written
+// as they arrive, fragments by gfx950's transposing LDS read (ds_read_b64_tr_b16), one register set, one barrier per
+// step (barrier -> split + write tile t+1 -> re-issue the loads of tile t+2 -> 12 MFMAs of tile t), split-K over the
+// grid with f32 atomics into the zeroed output.  32 KB of LDS (two fp16 planes per operand and buffer).
+#include <algorithm>
+#include <type_traits>
+
+#include "lkg_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, PLANE = BM * BK;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgArgs {
+    const float *a, *b;
+    long lda, ldb;
+    const float *a_colmax, *b_colmax;
+    float *c;
+    long ldc;
+    long m, n, k;
+    int tiles_m, tiles_n, k_splits;
+    int a_aligned, b_aligned;    // rows 16-byte aligned and k a multiple of 16: whole tiles may use unguarded 16-byte loads
+};
+
+// exponent e with max * 2^e in [2^13, 2^14)   (0 for max == 0 / denormal / non-finite; clamped so that ldexp stays finite)
+__device__ __forceinline__ int scale_exponent(float mx) {
+    const int ex = (__float_as_int(mx) >> 23) & 0xff;
+    if (ex == 0 || ex == 0xff) return 0;
+    return max(-100, min(100, 13 - (ex - 127)));
+}
+
+__device__ __forceinline__ int kmajor_off(int k, int c) {   // element offset of (k, c) inside a plane (lkg_gemm.hip)
+    return k * BM + ((((c >> 5) ^ (k & 3)) << 5) | (c & 31));
+}
+// plane, the 32 columns starting at c0 (a multiple of 32): this lane's column c0 + (lane & 31), k = 8 (lane >> 5) ..
+__device__ __forceinline__ f16x8 kmajor_frag(const _Float16 *plane, int c0, int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int col = c0 + (lane & 16) + 4 * pp;
+    const int k0 = 8 * (lane >> 5) + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(plane + kmajor_off(k0, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(plane + kmajor_off(k0 + 4, col)));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, both);
+}
+
+// 8 consecutive columns of one k row -> their hi / mid halves in the two planes of an operand
+// (the column scales 2^e come from LDS at every step: 16 registers held across the MFMA block would cost an occupancy step)
+__device__ __forceinline__ void split_store(const float (&v)[8], const float *scale8, _Float16 *planes, int t) {
+    typedef __fp16 fp16x8 __attribute__((ext_vector_type(8)));
+    fp16x8 hv, mv;
+    const float4 s0 = *reinterpret_cast<const float4 *>(scale8), s1 = *reinterpret_cast<const float4 *>(scale8 + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float a0 = v[j] * sc[j], a1 = v[j + 1] * sc[j + 1];
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+        const fp16x2 m = __builtin_amdgcn_cvt_pkrtz((a0 - (float)h[0]) * 2048.f, (a1 - (float)h[1]) * 2048.f);
+        hv[j] = h[0]; hv[j + 1] = h[1];
+        mv[j] = m[0]; mv[j + 1] = m[1];
+    }
+    _Float16 *p = planes + kmajor_off(t >> 4, (t & 15) * 8);
+    *reinterpret_cast<fp16x8 *>(p) = hv;
+    *reinterpret_cast<fp16x8 *>(p + PLANE) = mv;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_f16x2_kernel(WgArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2][2][2 * PLANE];     // [buffer][operand][hi, mid]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroup -> (k split, tile): consecutive workgroup ids go round the 8 XCDs, and every tile of a split re-reads the
+    // split's rows of one operand -- so all tiles of a split are placed on ONE XCD, next to each other in dispatch order:
+    // the re-reads hit that XCD's L2 instead of going to the fabric again (split = 8 * (slot / tiles) + xcd).
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (split >= g.k_splits) return;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+    const long per = ((g.k + g.k_splits - 1) / g.k_splits + BK - 1) / BK * BK;
+    const long k_lo = (long)split * per, k_hi = min(g.k, k_lo + per);
+    if (k_lo >= k_hi) return;
+
+    // this thread's 8 columns of either operand and their exponents (fixed for the whole k loop)
+    const int kr = t >> 4, c8 = (t & 15) * 8;
+    __shared__ __attribute__((aligned(16))) float scale_s[2][BM];              // 2^e of the tile's columns, per operand
+    if (t < BM) scale_s[0][t] = ldexpf(1.f, scale_exponent(g.a_colmax[min(m0 + t, g.m - 1)]));
+    else scale_s[1][t - BM] = ldexpf(1.f, scale_exponent(g.b_colmax[min(n0 + t - BM, g.n - 1)]));
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float la[8], lb[8];
+    auto load8 = [&](float (&v)[8], const float *src, long ld, long c0, long c_end, long k, bool fast) {
+        if (fast) {
+            const float4 *p = reinterpret_cast<const float4 *>(src + k * ld + c0 + c8);
+            const float4 x0 = p[0], x1 = p[1];
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        } else {
+            const float *row = src + min(k, k_hi - 1) * ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = row[min(c0 + c8 + j, c_end - 1)];
+                v[j] = (k < k_hi && c0 + c8 + j < c_end) ? x : 0.f;
+            }
+        }
+    };
+    auto stage = [&](_Float16 (*D)[2 * PLANE]) {     // one operand at a time: its planes are dead before the next split
+        split_store(la, scale_s[0] + c8, D[0], t);
+        __builtin_amdgcn_sched_barrier(0);
+        split_store(lb, scale_s[1] + c8, D[1], t);
+    };
+    auto mma = [&](const _Float16 (*S)[2 * PLANE]) {
+        f16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = kmajor_frag(S[0], wm * 64 + i * 32, lane);
+            bh[i] = kmajor_frag(S[1], wn * 64 + i * 32, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        const _Float16 sc = (_Float16)(1.f / 2048.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bm[i] = kmajor_frag(S[1] + PLANE, wn * 64 + i * 32, lane);
+            ah[i] = ah[i] * sc;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            am[i] = kmajor_frag(S[0] + PLANE, wm * 64 + i * 32, lane);
+            bh[i] = bh[i] * sc;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+    // fast_tag: bit 1 = the A tile is loaded with unguarded 16-byte loads, bit 0 = the B tile (compile-time constants: a
+    // runtime flag would put a branch around the loads and cost a vmcnt(0) per step).  An edge column tile (n = 300: the
+    // text-literal panel) keeps its other operand -- and every whole tile both -- on 16-byte loads this way.
+    // Every step is the same code; past the last tile the staged / fetched tiles are duplicates of it (in bounds, never
+    // multiplied).
+    auto pipeline = [&](auto fast_tag) {
+        constexpr int FAST = decltype(fast_tag)::value;
+        auto fetch = [&](long tile_k) {
+            const long k = k_lo + tile_k * BK + kr;
+            load8(la, g.a, g.lda, m0, g.m, k, (FAST & 2) != 0);
+            load8(lb, g.b, g.ldb, n0, g.n, k, (FAST & 1) != 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const long count = (k_hi - k_lo + BK - 1) / BK;
+        fetch(0);
+        stage(smem[0]);
+        fetch(min(1L, count - 1));
+        for (long it = 0; it < count; ++it) {
+            __syncthreads();
+            stage(smem[(it + 1) & 1]);
+            fetch(min(it + 2, count - 1));
+            mma(smem[it & 1]);
+        }
+    };
+    const bool a_fast = g.a_aligned && m0 + BM <= g.m, b_fast = g.b_aligned && n0 + BN <= g.n;
+    if (a_fast && b_fast) pipeline(std::integral_constant<int, 3>{});
+    else if (a_fast) pipeline(std::integral_constant<int, 2>{});
+    else if (b_fast) pipeline(std::integral_constant<int, 1>{});
+    else pipeline(std::integral_constant<int, 0>{});
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const bool atomic_out = g.k_splits > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const long row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            if (col >= g.n) continue;
+            const int ecol = scale_exponent(g.b_colmax[col]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (r & 3) + 8 * (r >> 2);
+                if (row >= g.m) continue;
+                const float v = ldexpf(acc[i][j][r], -(scale_exponent(g.a_colmax[row]) + ecol));
+                if (atomic_out) atomicAdd(g.c + row * g.ldc + col, v);
+                else g.c[row * g.ldc + col] = v;
+            }
+        }
+}
+
+// out[c] = max_r |x[r, c]|   (out is overwritten; non-negative floats order like their int bits)
+__global__ __launch_bounds__(256) void col_absmax_kernel(long n, int d, const float *__restrict__ x, long ldx,
+                                                          int *__restrict__ out, long rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;   // four rows in flight per thread
+        long r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            m0 = fmaxf(m0, fabsf(x[r * ldx + c]));
+            m1 = fmaxf(m1, fabsf(x[(r + 1) * ldx + c]));
+            m2 = fmaxf(m2, fabsf(x[(r + 2) * ldx + c]));
+            m3 = fmaxf(m3, fabsf(x[(r + 3) * ldx + c]));
+        }
+        for (; r < r1; ++r) m0 = fmaxf(m0, fabsf(x[r * ldx + c]));
+        atomicMax(out + c, __float_as_int(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3))));
+    }
+}
+
+}  // namespace
+
+extern "C" int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && ldx >= d && out, "lkg_col_absmax_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * d, s) != hipSuccess) {
+        lkg_set_error("lkg_col_absmax_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(x, "lkg_col_absmax_f32: null pointer");
+    const long blocks = std::min<int64_t>((n + 63) / 64, 2048);
+    const long rpb = (n + blocks - 1) / blocks;
+    hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (long)n, d, x, (long)ldx,
+                       reinterpret_cast<int *>(out), rpb);
+    LKG_CHECK_LAUNCH("lkg_col_absmax_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
+                                  const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc,
+                                  void *stream) {
+    LKG_REQUIRE(m >= 0 && n >= 0 && k >= 0, "lkg_gemm_wgrad_f32: negative size");
+    if (m == 0 || n == 0) return LKG_OK;
+    LKG_REQUIRE(c && ldc >= n, "lkg_gemm_wgrad_f32: bad C (ldc=%lld, n=%lld)", (long long)ldc, (long long)n);
+    hipStream_t s = (hipStream_t)stream;
+    WgArgs g{};
+    g.a = a; g.b = b; g.lda = lda; g.ldb = ldb; g.a_colmax = a_colmax; g.b_colmax = b_colmax; g.c = c; g.ldc = ldc;
+    g.m = m; g.n = n; g.k = k;
+    g.tiles_m = (int)((m + BM - 1) / BM);
+    g.tiles_n = (int)((n + BN - 1) / BN);
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    LKG_REQUIRE(tiles < INT32_MAX, "lkg_gemm_wgrad_f32: too many tiles");
+    int splits = 1;
+    if (tiles < 256 && k >= 8192) splits = (int)std::max<long>(1, std::min<long>(std::min<long>(1024 / tiles, k / 2048), 65535));
+    g.k_splits = splits;
+    if (splits > 1 || k == 0) {       // the partial sums meet in C by f32 atomics
+        const hipError_t rc = ldc == n ? hipMemsetAsync(c, 0, sizeof(float) * m * n, s)
+                                       : hipMemset2DAsync(c, sizeof(float) * ldc, 0, sizeof(float) * n, m, s);
+        if (rc != hipSuccess) {
+            lkg_set_error("lkg_gemm_wgrad_f32: hipMemsetAsync failed");
+            return LKG_ERR_HIP;
+        }
+        if (k == 0) return LKG_OK;
+    }
+    LKG_REQUIRE(a && b && a_colmax && b_colmax && lda >= m && ldb >= n, "lkg_gemm_wgrad_f32: null operand / leading dimension too small");
+    // unguarded 16-byte loads need aligned rows and whole k tiles in every split (whole column tiles: decided per tile)
+    g.a_aligned = k % BK == 0 && lda % 4 == 0 && lkg_aligned16(a);
+    g.b_aligned = k % BK == 0 && ldb % 4 == 0 && lkg_aligned16(b);
+    const long groups = ((long)splits + 7) / 8;          // (split, tile) pairs padded to whole rounds of the 8 XCDs
+    LKG_REQUIRE(groups * tiles * 8 < INT32_MAX, "lkg_gemm_wgrad_f32: grid too large");
+    hipLaunchKernelGGL(wgrad_f16x2_kernel, dim3((unsigned)(groups * tiles * 8)), dim3(256), 0, s, g);
+    LKG_CHECK_LAUNCH("lkg_gemm_wgrad_f32");
+    return LKG_OK;
+}

@@ -157,6 +157,50 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def col_absmax(x: torch.Tensor) -> torch.Tensor:
+    """out[c] = max_r |x[r, c]|: the column scales of lkg_gemm_wgrad_f32 for an operand nobody produced them for."""
+    _need_gpu(x)
+    x = _f32_rows(x)
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    N.call("lkg_col_absmax_f32", x.shape[0], x.shape[1], N.ptr(x), _ld(x), N.ptr(out), _stream())
+    return out
+
+
+def tag_colmax(t: torch.Tensor, cm: Optional[torch.Tensor]) -> torch.Tensor:
+    """Remember max |t[:, j]| on the tensor OBJECT (as tag_rowmax does for rows)."""
+    if cm is not None:
+        t._lkg_colmax = (t._version, cm)
+    return t
+
+
+def tagged_colmax(t: torch.Tensor, cache: bool = False) -> Optional[torch.Tensor]:
+    """The column maxima a producer left on t; with ``cache`` (constant tables: the literals) computed once and kept."""
+    tag = getattr(t, "_lkg_colmax", None)
+    if tag is not None and tag[0] == t._version and tag[1].shape[0] == t.shape[1] and tag[1].device == t.device:
+        return tag[1]
+    if not cache:
+        return None
+    cm = col_absmax(t)
+    try:
+        t._lkg_colmax = (t._version, cm)
+    except AttributeError:
+        pass
+    return cm
+
+
+def gemm_wgrad(a: torch.Tensor, b: torch.Tensor, a_colmax: torch.Tensor, b_colmax: torch.Tensor) -> torch.Tensor:
+    """a^T @ b over the rows (a: k x m, b: k x n) on the fp16 matrix cores (lkg_gemm_wgrad_f32); the column maxima of
+    both operands are inputs."""
+    _need_gpu(a, b, a_colmax, b_colmax)
+    a, b = _f32_rows(a), _f32_rows(b)
+    if a.shape[0] != b.shape[0]:
+        raise ValueError(f"gemm_wgrad: the operands have {a.shape[0]} and {b.shape[0]} rows")
+    out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    N.call("lkg_gemm_wgrad_f32", a.shape[1], b.shape[1], a.shape[0], N.ptr(a), _ld(a), N.ptr(a_colmax), N.ptr(b), _ld(b),
+           N.ptr(b_colmax), N.ptr(out), b.shape[1], _stream())
+    return out
+
+
 NARROW_PANEL = 8               # input panels this narrow take their weight gradient from lkg_colsum_weighted_f32
 
 

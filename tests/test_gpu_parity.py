@@ -1520,3 +1520,30 @@ def test_last_layer_backward_on_the_listed_rows_equals_the_dense_backward(ops, g
     for name, a, r in zip("x w b gamma beta".split(), res[1], res[0]):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), name
     assert float(res[1][0][flags == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 40_000), (512, 300, 33_333), (64, 2, 5000), (130, 257, 16 * 700 + 5)])
+def test_weight_gradient_f16x2_engine_is_f32_accurate(ops, gpu_device, m, n, k):
+    """lkg_gemm_wgrad_f32 (column-scaled exact fp16 hi/mid split, 3 MFMAs per product) against f64: within 3x of an f32
+    GEMM's own error, also with columns 40 orders of magnitude apart, rows that are almost all zero, strided views."""
+    torch.manual_seed(m + n)
+    a = torch.randn(k, m + 4, device=gpu_device)[:, 2:2 + m]
+    b = torch.randn(k, n, device=gpu_device)
+    col_scale_a = torch.logspace(-20, 20, m, device=gpu_device)
+    for variant in ("plain", "columns 1e-20 .. 1e20", "row-sparse"):
+        aa, bb = a, b
+        if variant != "plain":
+            aa = a * col_scale_a
+        if variant == "row-sparse":
+            keep = torch.zeros(k, 1, device=gpu_device)
+            keep[torch.randint(0, k, (k // 100,), device=gpu_device)] = 1
+            aa = aa * keep
+        got = ops.gemm_wgrad(aa, bb, ops.col_absmax(aa), ops.col_absmax(bb)).double()
+        want = aa.double().t() @ bb.double()
+        ref32 = (aa.t() @ bb).double()                      # hipBLASLt f32
+        scale = aa.double().abs().t() @ bb.double().abs() + 1e-300          # componentwise error scale of a dot product
+        e_got = float(((got - want).abs() / scale).max())
+        e_f32 = float(((ref32 - want).abs() / scale).max())
+        assert e_got <= max(3 * e_f32, 4e-7), (variant, e_got, e_f32)     # (the split products carry 2^-22)
+    cm = ops.col_absmax(a)
+    assert torch.equal(cm.cpu(), a.abs().amax(0).cpu())

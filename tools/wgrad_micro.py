@@ -14,4 +14,9 @@ for m, k in ((256, 256), (512, 256), (512, 300)):
     t = tm(lambda: ops.gemm(g, x, trans_a=True))
     want = g[:, :8].double().t() @ x.double()
     err = float((out[:8].double() - want).abs().max() / want.abs().max())
-    print(f"dW[{m} x {k}] over {n} rows: {t:.3f} ms  {2*n*m*k/t/1e9:.0f} TF f32-eq  rel err {err:.2e}")
+    print(f"dW[{m} x {k}] over {n} rows: bf16x3 {t:.3f} ms  {2*n*m*k/t/1e9:.0f} TF f32-eq  rel err {err:.2e}")
+    ca, cb = ops.col_absmax(g), ops.col_absmax(x)
+    out2 = ops.gemm_wgrad(g, x, ca, cb)
+    t2 = tm(lambda: ops.gemm_wgrad(g, x, ca, cb))
+    err2 = float((out2[:8].double() - want).abs().max() / want.abs().max())
+    print(f"                         f16x2  {t2:.3f} ms  {2*n*m*k/t2/1e9:.0f} TF f32-eq  rel err {err2:.2e}")
