@@ -293,3 +293,4 @@ extern "C" int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *
     LKG_CHECK_LAUNCH("lkg_gemm_wgrad_f32");
     return LKG_OK;
 }
+
