@@ -143,13 +143,17 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
  *   x_rows, self_rows  (nullable, uint8 per row of x / of self) a zero byte promises that the row is all zero: its
  *                      entries are skipped without touching x (16-byte path; otherwise ignored).  The backward of the
  *                      LAST aggregation layer: the loss's gradient reaches <= 3B of the N rows, so all but a fraction
- *                      of a percent of the transpose SpMM's gathers would fetch zeros.                          */
+ *                      of a percent of the transpose SpMM's gathers would fetch zeros;
+ *   out_rows           (nullable, uint8[n_rows], cleared here; needs x_rows, the 16-byte path and d > 32) receives 1
+ *                      for every row that got a contribution (a flagged entry, a flagged self / add2 row); the OTHER
+ *                      rows of out are not written: out is a table the caller keeps all-zero there.  The set of
+ *                      flagged rows is the gradient's next frontier, handed on to the layer below.               */
 int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int32_t *col,
                            const float *val, const float *x, int64_t ldx, float *out, int64_t ldo,
                            const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                            const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src, float *copy_dst,
                            int64_t ld_copy_dst, float *rowmax_out, const uint8_t *x_rows, const uint8_t *self_rows,
-                           const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
+                           uint8_t *out_rows, const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream);
 
 /* Batch-pruned step (exact; literalkg_amd/pruned.py): the loss reads <= 3B rows of the last layer, so a
  * layer only needs the rows its consumers read.  lkg_csr_extract_rows copies the entries of the (sorted,
@@ -346,8 +350,9 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
  * row-sparse gradient, lkg_fill_rows_f32) -- those rows skip the g_yn / y reads, and with g_y == NULL the whole
  * row (g_z = 0, no z read either).  sparse_out != 0 (needs g_yn_rows, g_y == NULL, g_z_rowmax == NULL): g_z is a
  * table the caller keeps all-zero outside the flagged rows, so the zero rows are not written either; row_ids
- * (nullable, int64[n_row_ids], with sparse_out) then lists the flagged rows (negative entries = padding) and only
- * those are visited: the launch is over the <= 3B rows the loss reaches instead of N.                        */
+ * (nullable, int64[n_row_ids], with sparse_out) then lists the rows to visit (negative entries = padding): the launch
+ * is over the <= 3B rows the loss reaches -- or over the gradient's frontier, when g_y is row-sparse too (its rows
+ * must then be in the list; g_y is read for every listed row) -- instead of N.                              */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,

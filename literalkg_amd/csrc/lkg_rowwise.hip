@@ -407,8 +407,8 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                                          float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax,
                                          const uint8_t *g_yn_rows, int32_t sparse_out, const int64_t *row_ids,
                                          int64_t n_row_ids, void *stream) {
-    LKG_REQUIRE(!sparse_out || (g_yn_rows && g_yn && !g_y && !g_z_rowmax),
-                "lkg_act_layernorm_bwd_f32: sparse_out needs row flags, no g_y and no row maxima");
+    LKG_REQUIRE(!sparse_out || (!g_z_rowmax && (row_ids || (g_yn_rows && g_yn && !g_y))),
+                "lkg_act_layernorm_bwd_f32: sparse_out needs a row list, or row flags and no g_y; and no row maxima");
     LKG_REQUIRE(!row_ids || (sparse_out && n_row_ids >= 0), "lkg_act_layernorm_bwd_f32: a row list needs sparse_out");
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");

@@ -119,7 +119,7 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
 // (64 / LPE flagged entries at a time, one per sub-group).  Four chunks are in flight so that the dependent col -> flag
 // round trips of a long row overlap.
 template <typename V, int LPE, int CPL, bool FULL>
-__device__ __forceinline__ void accumulate_entries_flagged(V (&acc)[CPL], int start, int end, int wave_i, int n_waves,
+__device__ __forceinline__ bool accumulate_entries_flagged(V (&acc)[CPL], int start, int end, int wave_i, int n_waves,
                                                            int lane, int nchunk, const int *__restrict__ col,
                                                            const float *__restrict__ val, const float *__restrict__ x,
                                                            long ldx, const unsigned char *__restrict__ xflags) {
@@ -127,6 +127,7 @@ __device__ __forceinline__ void accumulate_entries_flagged(V (&acc)[CPL], int st
     constexpr int EPW = 64 / LPE, G = 4;
     const int sub = lane / LPE;
     const int sl = lane % LPE;
+    bool any = false;                              // did this wave meet a flagged entry?  (wave-uniform)
     for (int base0 = start + 64 * wave_i; base0 < end; base0 += 64 * n_waves * G) {
         int c[G];
         unsigned long long live[G];
@@ -144,6 +145,7 @@ __device__ __forceinline__ void accumulate_entries_flagged(V (&acc)[CPL], int st
         for (int gq = 0; gq < G; ++gq) {
             unsigned long long m = live[gq];
             if (m == 0) continue;                                  // (wave-uniform)
+            any = true;
             const int j = base0 + 64 * n_waves * gq + lane;
             const float v = val[min(j, end - 1)];
             while (m) {
@@ -170,6 +172,7 @@ __device__ __forceinline__ void accumulate_entries_flagged(V (&acc)[CPL], int st
             }
         }
     }
+    return any;
 }
 
 // Optional row-wise extras of the epilogue (lkg_spmm_csr_fused_f32): a second addend and a row copy riding along.
@@ -184,6 +187,8 @@ struct SpmmExtra {
     int *rowmax;             // rowmax[i] = max |out[i,:]| as the int bits of a non-negative float (atomicMax over the slabs)
     const unsigned char *x_rows;      // nullable: rows of x that may be non-zero (accumulate_entries_flagged)
     const unsigned char *self_rows;   // nullable: the same promise for `self`
+    unsigned char *out_rows;          // nullable (with x_rows): out_rows[i] = 1 where row i received a contribution; the other
+                                      //   rows are NOT written (out is a table the caller keeps all-zero there)
     __device__ __forceinline__ const float *add2_row(long row) const {
         return add2 && (!add2_rows || add2_rows[row]) ? add2 + row * ld_add2 : nullptr;
     }
@@ -241,9 +246,10 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
     V acc[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = ops::zero();
+    bool any = true;
     if constexpr (XF)
-        accumulate_entries_flagged<V, LPE, CPL, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val,
-                                                      x, ldx, ex.x_rows);
+        any = accumulate_entries_flagged<V, LPE, CPL, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col,
+                                                            val, x, ldx, ex.x_rows);
     else
         accumulate_entries<V, LPE, CPL, U, FULL>(acc, start, end, team ? w : 0, team ? 4 : 1, lane, nchunk, col, val, x,
                                                  ldx);
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
         if (lane < LPE)
 #pragma unroll
             for (int i = 0; i < CPL; ++i) part[w][i][lane] = acc[i];
-        __syncthreads();
+        any = __syncthreads_or(any);
         if (w != 0) return;
         if (lane < LPE)
 #pragma unroll
@@ -268,6 +274,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
         V *dst = reinterpret_cast<V *>(out + (long)row * ldo);
         const V *own = self && (!ex.self_rows || ex.self_rows[row]) ? reinterpret_cast<const V *>(self + (long)row * ld_self) : nullptr;
         const V *own2 = reinterpret_cast<const V *>(ex.add2_row(row));
+        if constexpr (XF) {
+            if (ex.out_rows) {       // row-sparse output: flag the rows that received anything, leave the others alone
+                if (!(any || own || own2)) return;
+                if (lane == 0) ex.out_rows[row] = 1;
+            }
+        }
         const V *csrc = ex.copy_dst ? reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src) : nullptr;
         V *cdst = ex.copy_dst ? reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst) : nullptr;
 #pragma unroll
@@ -464,8 +476,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                                       const float *self, int64_t ld_self, const float *add2, int64_t ld_add2,
                                       const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src,
                                       float *copy_dst, int64_t ld_copy_dst, float *rowmax_out, const uint8_t *x_rows,
-                                      const uint8_t *self_rows, const int32_t *long_rows, int32_t n_long,
-                                      int32_t long_thresh, void *stream) {
+                                      const uint8_t *self_rows, uint8_t *out_rows, const int32_t *long_rows,
+                                      int32_t n_long, int32_t long_thresh, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -488,8 +500,14 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
         return LKG_ERR_HIP;
     }
+    LKG_REQUIRE(!out_rows || (x_rows && vec && !rowmax_out && d > 32),
+                "lkg_spmm_csr_fused_f32: out_rows needs x_rows, the 16-byte path (d %% 4 == 0, aligned rows), d > 32 and no rowmax_out");
+    if (out_rows && hipMemsetAsync(out_rows, 0, n_rows, s) != hipSuccess) {
+        lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
     const SpmmExtra ex{add2, (long)ld_add2, add2 ? add2_rows : nullptr, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
-                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr};
+                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows};
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
     // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
@@ -508,7 +526,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr,
                             copy_dst ? copy_src + c0 : nullptr,
                             (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst,
-                            reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr};
+                            reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
                                         self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
@@ -523,7 +541,7 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                 const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                                 int32_t long_thresh, void *stream) {
     return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr,
-                                  nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, long_rows, n_long, long_thresh, stream);
+                                  nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, long_rows, n_long, long_thresh, stream);
 }
 
 // dst[i] = src[perm[i]]

@@ -99,13 +99,15 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
              add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
              copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None,
-             x_rows: Optional[torch.Tensor] = None, self_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+             x_rows: Optional[torch.Tensor] = None, self_rows: Optional[torch.Tensor] = None,
+             out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
     epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own).  add2_rows /
     x_rows / self_rows (uint8 per row of add2 / x / add_self): the operand is zero outside the flagged rows and is read
-    there only (x_rows is indexed like x: by col - x_row_offset)."""
+    there only (x_rows is indexed like x: by col - x_row_offset).  out_rows (uint8 per output row, with x_rows): receives
+    1 where a row got a contribution; the other rows of ``out`` are NOT written (the caller keeps them zero)."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -123,7 +125,7 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
            _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
            N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
            N.ptr(rowmax), (x_rows.data_ptr() - x_row_offset) if x_rows is not None else None,
-           N.ptr(self_rows if add_self is not None else None), N.ptr(long_rows),
+           N.ptr(self_rows if add_self is not None else None), N.ptr(out_rows), N.ptr(long_rows),
            0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
     return out
 
@@ -201,6 +203,7 @@ def gemm_wgrad(a: torch.Tensor, b: torch.Tensor, a_colmax: torch.Tensor, b_colma
     return out
 
 
+FRONTIER_GROWTH = 24           # a row set is followed through one more transpose SpMM while it is this many times smaller than N
 NARROW_PANEL = 8               # input panels this narrow take their weight gradient from lkg_colsum_weighted_f32
 
 
@@ -275,11 +278,11 @@ class RowSet:
     row) is what the kernels look at; ``compact_ids()`` lists every such row exactly once (no host sync: the list has the
     length of the id lists it came from, duplicates replaced by -1, which the row kernels skip)."""
 
-    def __init__(self, flags: torch.Tensor, id_lists: Sequence[torch.Tensor]):
+    def __init__(self, flags: torch.Tensor, id_lists: Sequence[torch.Tensor], unique: bool = False):
         self.flags = flags
         self.id_lists = [i.reshape(-1) for i in id_lists]
         self.n_max = sum(i.numel() for i in self.id_lists)
-        self._ids = None
+        self._ids = self.id_lists[0] if (unique and len(self.id_lists) == 1) else None
 
     def compact_ids(self) -> torch.Tensor:
         if self._ids is None:       # (index bookkeeping over <= 3B ids)
@@ -288,6 +291,18 @@ class RowSet:
             dup[1:] = s_[1:] == s_[:-1]
             self._ids = torch.where(dup, torch.full_like(s_, -1), s_)
         return self._ids
+
+
+def union_rows(a: Optional[RowSet], b: Optional[RowSet]) -> Optional[RowSet]:
+    """The rows of a or b (either may be None = no such gradient).  The flags of ``a`` are extended in place: they are
+    the per-backward array a frontier SpMM produced, nobody else looks at them afterwards."""
+    if a is None or b is None:
+        return a if b is None else b
+    if a is b:
+        return a
+    for ids in b.id_lists:
+        N.call("lkg_fill_rows_f32", ids.numel(), 0, N.ptr(ids), None, 0, 0.0, N.ptr(a.flags), 1, _stream())
+    return RowSet(a.flags, [a.compact_ids(), *b.id_lists])
 
 
 def tag_rows(t: torch.Tensor, rows: Optional[RowSet]) -> torch.Tensor:
@@ -534,8 +549,23 @@ class _Aggregate(Function):
         g = ctx.g
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
-        rows = _flags(tagged_rows(grad))      # the last layer's gradient: all but <= 3B rows are zero and are not gathered
+        rs = tagged_rows(grad)                # the last layer's gradient: all but <= 3B rows are zero and are not gathered
+        rows = _flags(rs)
         grad = _f32_rows(grad)
+        d = grad.shape[1]
+        if (rows_worth_compacting(rs, g.n) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0 and d > 32
+                and grad.data_ptr() % 16 == 0 and _ld(grad) % 4 == 0):
+            # ... and the rows it reaches in turn (the gradient's frontier) are few as well: the result goes into a table kept
+            # all-zero elsewhere, the kernel flags the rows it wrote, and the layer below works on those (one host sync: their
+            # number decides the shapes of its products)
+            ent = _RowScratch.acquire(g.n, d, grad.device, "g_agg")
+            out = ent.buf.view(ent.buf.shape)
+            reached = torch.empty(g.n, dtype=torch.uint8, device=grad.device)
+            spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, out=out, long_rows=g.long_rows(True),
+                     add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows, out_rows=reached)
+            ids = torch.nonzero(reached).flatten()
+            ent.dirty.append(ids)
+            return tag_rows(out, RowSet(reached, [ids], unique=True)), None, None, None, None
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True),
                         add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows), None, None, None, None
 
@@ -793,14 +823,19 @@ class _ActLayerNorm(Function):
         none = (None,) * 10
         if gy is None and gyn is None:
             return none
-        rows = tagged_rows(gyn)          # a loss's row-sparse gradient: the kernel skips the zero rows
+        rows_n = tagged_rows(gyn)        # a loss's row-sparse gradient: the kernel skips the zero rows
+        rows_y = tagged_rows(gy)         # the frontier a transpose SpMM over row-sparse input reached
         gy = _f32_rows(gy) if gy is not None else None
         gyn = _f32_rows(gyn) if gyn is not None else None
         gg = torch.zeros(d, dtype=torch.float32, device=z.device)
         gb = torch.zeros(d, dtype=torch.float32, device=z.device)
-        # the LAST layer (no g_y): g_z is zero outside those rows too -- it goes into a table kept all-zero between steps
-        # (only the listed rows are written) and carries the row set on to the Linear's backward and the transpose SpMM
-        sparse_out = gy is None and rows_worth_compacting(rows, n)
+        # no gradient outside a few rows (the LAST layer: g_yn's rows, no g_y; the layer below: + the frontier g_y reaches):
+        # g_z is zero outside them too -- it goes into a table kept all-zero between steps (only the listed rows are visited)
+        # and carries the row set on to the Linear's backward and the transpose SpMM
+        rows = None
+        if (gy is None or rows_y is not None) and (gyn is None or rows_n is not None):
+            rows = union_rows(rows_y, rows_n)
+        sparse_out = rows_worth_compacting(rows, n)
         ids = rows.compact_ids() if sparse_out else None
         if sparse_out:
             gz, rm = zero_table_for(rows, n, d, z.device, "g_z"), None
@@ -810,7 +845,7 @@ class _ActLayerNorm(Function):
         N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
                N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
-               float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows)), int(sparse_out),
+               float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows_n)), int(sparse_out),
                N.ptr(ids) if sparse_out else None, ids.numel() if sparse_out else 0, _stream())
         return (tag_rowmax(gz, rm), gg, gb) + none[3:]
 

@@ -1547,3 +1547,44 @@ def test_weight_gradient_f16x2_engine_is_f32_accurate(ops, gpu_device, m, n, k):
         assert e_got <= max(3 * e_f32, 4e-7), (variant, e_got, e_f32)     # (the split products carry 2^-22)
     cm = ops.col_absmax(a)
     assert torch.equal(cm.cpu(), a.abs().amax(0).cpu())
+
+
+def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_device):
+    """Two aggregation layers under a loss on a few rows: the last layer's backward runs on those rows, the transpose SpMM
+    hands the rows it reached (the frontier, flagged by the kernel) to the layer below, which runs on them as well.  All
+    parameter gradients against the same model with the row-sparse machinery switched off."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e, dim = 60_000, 240_000, 64
+    h, t, r = make_kg(n, e, seed=11)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, aggregation_type="gcn",
+                        kg_l2loss_lambda=1e-4, device=gpu_device)
+    torch.manual_seed(1)
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), None, None, scoring="transr").to(gpu_device).eval()
+    batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 40, 3, seed=2)]
+    seen = {}
+    real = ops._MultiLinear._backward_on_rows
+
+    def spy(ctx, gy, rows, xs, ws):
+        seen[gy.shape[0], rows.n_max] = seen.get((gy.shape[0], rows.n_max), 0) + 1
+        return real(ctx, gy, rows, xs, ws)
+
+    def grads(sparse):
+        m.zero_grad(set_to_none=True)
+        m._table_grad_stays_inside = (lambda: m.gat_rows is None) if sparse else (lambda: False)
+        m(*batch, device=gpu_device, mode="pre_training").backward()
+        return {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    ops._MultiLinear._backward_on_rows = staticmethod(spy)
+    try:
+        got = grads(True)
+    finally:
+        ops._MultiLinear._backward_on_rows = staticmethod(real)
+    want = grads(False)
+    del m._table_grad_stays_inside
+    assert len(seen) == 2, seen                 # both Linears took the rows path: 120 + 2 * 40 ids, then the frontier
+    assert got.keys() == want.keys()
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) <= 5e-5 * scale, k
+    ops._RowScratch._tables.clear()
