@@ -550,7 +550,7 @@ class _Aggregate(Function):
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
         rs = tagged_rows(grad)                # the last layer's gradient: all but <= 3B rows are zero and are not gathered
-        rows = _flags(rs)
+        rows = _flags(rs) if rows_worth_compacting(rs, g.n) else None      # (a dense-ish row set: the plain kernel is faster)
         grad = _f32_rows(grad)
         d = grad.shape[1]
         if (rows_worth_compacting(rs, g.n) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0 and d > 32
@@ -604,7 +604,8 @@ class _AggregateKeep(Function):
             return g_kept, None, None, None, None, None
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
-        rows = _flags(tagged_rows(g_side))
+        rs = tagged_rows(g_side)
+        rows = _flags(rs) if rows_worth_compacting(rs, g.n) else None
         g_side = _f32_rows(g_side)
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
                         add_self=g_side if ctx.plus_self else None, add2=g_kept,
