@@ -346,6 +346,7 @@ class _RowScratch:
     fresh one replaces it."""
 
     _tables: dict = {}
+    MAX_TABLES = 8
 
     def __init__(self, shape, device, with_flags: bool):
         self.buf = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
@@ -356,9 +357,12 @@ class _RowScratch:
     @classmethod
     def acquire(cls, n: int, c: int, device, pool: str = "loss") -> "_RowScratch":
         key = (device, n, c, pool)
-        ent = cls._tables.get(key)
+        ent = cls._tables.pop(key, None)
         if ent is None or _storage_users(ent.buf) != ent.users:
-            ent = cls._tables[key] = _RowScratch((n, c), device, pool == "loss")
+            ent = _RowScratch((n, c), device, pool == "loss")
+        cls._tables[key] = ent                       # (most recently used last)
+        while len(cls._tables) > cls.MAX_TABLES:     # another model / shape: let the oldest table go
+            cls._tables.pop(next(iter(cls._tables)))
         for ids in ent.dirty:
             N.call("lkg_fill_rows_f32", ids.numel(), ent.buf.shape[1], N.ptr(ids), N.ptr(ent.buf), _ld(ent.buf), 0.0,
                    N.ptr(ent.flags), 0, _stream())
