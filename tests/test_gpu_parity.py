@@ -1549,7 +1549,9 @@ def test_weight_gradient_f16x2_engine_is_f32_accurate(ops, gpu_device, m, n, k):
     assert torch.equal(cm.cpu(), a.abs().amax(0).cpu())
 
 
-def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_device):
+@pytest.mark.parametrize("agg,residual,n_rows_paths", [("gcn", False, 2), ("graphsage", False, None), ("gcn", True, None),
+                                                       ("bi-interaction", False, None)])
+def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_device, agg, residual, n_rows_paths):
     """Two aggregation layers under a loss on a few rows: the last layer's backward runs on those rows, the transpose SpMM
     hands the rows it reached (the frontier, flagged by the kernel) to the layer below, which runs on them as well.  All
     parameter gradients against the same model with the row-sparse machinery switched off."""
@@ -1557,8 +1559,8 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
     from literalkg_amd import io
     n, e, dim = 60_000, 240_000, 64
     h, t, r = make_kg(n, e, seed=11)
-    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, aggregation_type="gcn",
-                        kg_l2loss_lambda=1e-4, device=gpu_device)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, aggregation_type=agg,
+                        use_residual=residual, kg_l2loss_lambda=1e-4, device=gpu_device)
     torch.manual_seed(1)
     m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), None, None, scoring="transr").to(gpu_device).eval()
     batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 40, 3, seed=2)]
@@ -1582,7 +1584,8 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
         ops._MultiLinear._backward_on_rows = staticmethod(real)
     want = grads(False)
     del m._table_grad_stays_inside
-    assert len(seen) == 2, seen                 # both Linears took the rows path: 120 + 2 * 40 ids, then the frontier
+    if n_rows_paths is not None:                # both layers' Linears took the rows path: 120 + 2 * 40 ids, then the frontier
+        assert len({k[1] for k in seen}) == n_rows_paths, seen
     assert got.keys() == want.keys()
     for k in want:
         scale = float(want[k].abs().max()) + 1e-30
