@@ -384,6 +384,13 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
  * the operand's producer -- lkg_gate_blend_bwd_f32, lkg_row_absmax_f32 -- or lkg_col_absmax_f32 for constant tables). */
 int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
                        const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc, void *stream);
+/* The same product without scales ("bf16 x 3", six bf16 MFMAs per product as in lkg_gemm_f32) on a 256 x 128 tile per
+ * CU with three tiles of loads in flight and the split hidden behind the MFMAs: the long-k engine of every wide weight
+ * gradient of the path.  lkg_gemm_longk_ok tells whether it takes a product (k >= 8192 in whole 16-row tiles, widths and row strides
+ * multiples of 4 floats, 16-byte aligned operands); otherwise lkg_gemm_f32(trans_a = 1) serves it.  C is overwritten.  */
+int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
+int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                       float *c, int64_t ldc, void *stream);
 /* out[c] = max_r |x[r,c]|  (out is overwritten)                                                     */
 int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 

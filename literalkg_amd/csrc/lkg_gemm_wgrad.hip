@@ -294,3 +294,250 @@ extern "C" int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *
     return LKG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product without scales: "bf16 x 3" (every f32 is the exact sum of three bf16, six bf16 MFMAs per product:
+// lkg_gemm.hip) on a 256 x 128 tile per CU fed by an LDS-DMA ring.
+//
+// The 128 x 128 long-k engines request every operand once per tile of the other (4 GB for a 256 x 256 gradient over
+// 1 M rows) and run at 4.6-5.4 TB/s of requests with the matrix pipe a quarter busy.  Here one 8-wave workgroup owns a
+// CU: 256 columns of A x 128 of B (25-45 % fewer requested bytes), THREE register sets of raw pieces keep three tiles
+// (72 KB per CU) in flight, and the thread that loaded a piece splits it three ways and writes the bf16 planes in the
+// shadow of the step's 24 MFMAs: the split is cut into 21 slices of <= 5 VALU instructions, one behind each MFMA (an MFMA
+// holds the issue port for 8 of its 32 cycles), the 22nd re-issues the set's loads.  (An LDS-DMA ring instead of the
+// register sets was measured first: the three DMA issues per wave and step cost more than they saved -- 0.99 ms.)
+// LDS: planes 2 x 36 KB.  k must be a multiple of 16 (the caller falls back otherwise).
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RM = 256, RN = 128, RK = 16;
+constexpr int RA_PLANE = RM * RK, RB_PLANE = RN * RK;                 // bf16 elements per plane
+constexpr int RBUF = 3 * (RA_PLANE + RB_PLANE);                       // bf16 elements per plane buffer (36 KB)
+
+template <int COLS>
+__device__ __forceinline__ int roff(int k, int c) {   // element (k, c) of a [16 k][COLS] plane: 64-byte chunks XORed with k & 3
+    return k * COLS + ((((c >> 5) ^ (k & 3)) << 5) | (c & 31));
+}
+template <int COLS>
+__device__ __forceinline__ bf16x8 rfrag(const __bf16 *plane, int c0, int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int col = c0 + (lane & 16) + 4 * pp;
+    const int k0 = 8 * (lane >> 5) + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(plane + roff<COLS>(k0, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(plane + roff<COLS>(k0 + 4, col)));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_longk_kernel(WgArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char longk_smem[];
+    __bf16 *planes = reinterpret_cast<__bf16 *>(longk_smem);                      // [2][A hi mid lo | B hi mid lo]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                      // all tiles of a k split on one XCD (above)
+    const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (split >= g.k_splits) return;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const long m0 = (long)tm * RM, n0 = (long)tn * RN;
+    const long per = ((g.k + g.k_splits - 1) / g.k_splits + RK - 1) / RK * RK;
+    const long k_lo = (long)split * per, k_hi = min(g.k, k_lo + per);            // (whole k tiles: k % 16 == 0)
+    if (k_lo >= k_hi) return;
+    const int count = (int)((k_hi - k_lo) / RK);
+
+    // this thread's pieces (4 consecutive columns of one k row): A pieces t and t + 512 (k rows t >> 6 and 8 + (t >> 6),
+    // columns 4 (t & 63) ..), B piece t (k row t >> 5, columns 4 (t & 31) ..).  A piece past the operand's width is
+    // requested from its last valid piece instead and zeroed (bit mask) when it is split.
+    const int ka = t >> 6, ca = 4 * (t & 63), kb = t >> 5, cb = 4 * (t & 31);
+    const int keep_a = (m0 + ca + 3 < g.m) ? -1 : 0, keep_b = (n0 + cb + 3 < g.n) ? -1 : 0;
+    const float *pa0 = g.a + (k_lo + ka) * g.lda + min(m0 + ca, g.m - 4);
+    const float *pa1 = pa0 + 8 * g.lda;
+    const float *pb = g.b + (k_lo + kb) * g.ldb + min(n0 + cb, g.n - 4);
+    const long step_a = RK * g.lda, step_b = RK * g.ldb;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // THREE register sets of raw pieces: the loads of tile t+4 are issued when the split of tile t+1 has freed its set --
+    // three tiles (72 KB per CU) in flight, counted vmcnt waits by the compiler (plain loads only)
+    f32x4 rs0[3], rs1[3], rs2[3];
+    int fetched = 0;                             // k tiles requested so far (past the last one the last is requested again)
+    auto fetch = [&](f32x4 (&r)[3]) {
+        r[0] = *reinterpret_cast<const f32x4 *>(pa0);
+        r[1] = *reinterpret_cast<const f32x4 *>(pa1);
+        r[2] = *reinterpret_cast<const f32x4 *>(pb);
+        ++fetched;
+        const bool more = fetched < count;       // (wave-uniform)
+        pa0 += more ? step_a : 0;
+        pa1 += more ? step_a : 0;
+        pb += more ? step_b : 0;
+    };
+
+    // ---- the split of one element pair, in three slices of <= 5 VALU instructions (x -> hi, mid, lo; packed conversions)
+    f32x2 px[6];                                  // pair q: piece q >> 1, elements 2 (q & 1), 2 (q & 1) + 1
+    bf16x2 ph[6], pm[6], pl[6];
+    auto s1 = [&](const f32x4 (&r)[3], int q, int live) {
+        const f32x4 v = r[q >> 1];
+        const int keep = ((q >> 1) == 2 ? keep_b : keep_a) & live;
+        px[q][0] = __int_as_float(__float_as_int(v[2 * (q & 1)]) & keep);
+        px[q][1] = __int_as_float(__float_as_int(v[2 * (q & 1) + 1]) & keep);
+        ph[q] = __builtin_convertvector(px[q], bf16x2);
+    };
+    auto s2 = [&](int q) {
+        px[q] = px[q] - __builtin_convertvector(ph[q], f32x2);
+        pm[q] = __builtin_convertvector(px[q], bf16x2);
+    };
+    auto s3 = [&](int q) {
+        px[q] = px[q] - __builtin_convertvector(pm[q], f32x2);
+        pl[q] = __builtin_convertvector(px[q], bf16x2);
+    };
+    const int off_a0 = roff<RM>(ka, ca), off_a1 = roff<RM>(ka + 8, ca), off_b = roff<RN>(kb, cb);
+    auto write_piece = [&](int p, __bf16 *D) {    // piece p of the next tile -> its three planes
+        __bf16 *plane0 = p == 2 ? D + 3 * RA_PLANE : D;
+        const int pe = p == 2 ? RB_PLANE : RA_PLANE, off = p == 0 ? off_a0 : (p == 1 ? off_a1 : off_b);
+        const bf16x4 h = {ph[2 * p][0], ph[2 * p][1], ph[2 * p + 1][0], ph[2 * p + 1][1]};
+        const bf16x4 m = {pm[2 * p][0], pm[2 * p][1], pm[2 * p + 1][0], pm[2 * p + 1][1]};
+        const bf16x4 l = {pl[2 * p][0], pl[2 * p][1], pl[2 * p + 1][0], pl[2 * p + 1][1]};
+        *reinterpret_cast<bf16x4 *>(plane0 + off) = h;
+        *reinterpret_cast<bf16x4 *>(plane0 + pe + off) = m;
+        *reinterpret_cast<bf16x4 *>(plane0 + 2 * pe + off) = l;
+    };
+    // slice number `i` of the 22 that follow the MFMAs (pairs in order; a piece is written once both its pairs are split;
+    // the last one re-issues the set's loads)
+    auto slice = [&](f32x4 (&r)[3], int i, __bf16 *D, int live) {
+        if (i == 21) { fetch(r); return; }
+        if (i > 21) return;
+        const int p = i / 7, rr = i % 7;           // per piece: s1 s1 s2 s2 s3 s3 write
+        if (rr < 2) s1(r, 2 * p + rr, live);
+        else if (rr < 4) s2(2 * p + rr - 2);
+        else if (rr < 6) s3(2 * p + rr - 4);
+        else write_piece(p, D);
+    };
+#define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
+#define LKG_MF(I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[I][PA], b[J][PB], acc[I][J], 0, 0, 0)
+#define LKG_TERM4(PA, PB, S0)                                                                                       \
+    LKG_MF(0, 0, PA, PB); slice(r, S0, D, live); LKG_PIN(); LKG_MF(0, 1, PA, PB); slice(r, S0 + 1, D, live); LKG_PIN();  \
+    LKG_MF(1, 0, PA, PB); slice(r, S0 + 2, D, live); LKG_PIN(); LKG_MF(1, 1, PA, PB); slice(r, S0 + 3, D, live); LKG_PIN();
+    // the 24 MFMAs of the tile in S with the split of the next tile (register set r -> D; live = 0: past the last tile,
+    // zero planes) sliced between them
+    auto step = [&](const __bf16 *S, __bf16 *D, f32x4 (&r)[3], int live) {
+        const __bf16 *SA = S, *SB = S + 3 * RA_PLANE;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i][2] = rfrag<RM>(SA + 2 * RA_PLANE, wm * 64 + i * 32, lane);
+            b[i][0] = rfrag<RN>(SB, wn * 64 + i * 32, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i][0] = rfrag<RM>(SA, wm * 64 + i * 32, lane);
+            b[i][2] = rfrag<RN>(SB + 2 * RB_PLANE, wn * 64 + i * 32, lane);
+            a[i][1] = rfrag<RM>(SA + RA_PLANE, wm * 64 + i * 32, lane);
+            b[i][1] = rfrag<RN>(SB + RB_PLANE, wn * 64 + i * 32, lane);
+        }
+        LKG_PIN();
+        LKG_TERM4(2, 0, 0)
+        LKG_TERM4(0, 2, 4)
+        LKG_TERM4(1, 1, 8)
+        LKG_TERM4(1, 0, 12)
+        LKG_TERM4(0, 1, 16)
+        LKG_TERM4(0, 0, 20)
+    };
+#undef LKG_TERM4
+#undef LKG_MF
+#undef LKG_PIN
+
+    // Tile j lives in register set j % 3.  Step t: barrier (tile t complete in planes t & 1) -> MFMAs of tile t with the
+    // split of tile t+1 and, behind it, the loads of tile t+4 into the same set.  The loop runs in threes (static set
+    // names); the up to two extra steps multiply planes that were staged as zeros (live = 0).
+    fetch(rs0);
+    fetch(rs1);
+    fetch(rs2);
+    for (int i = 0; i < 21; ++i) slice(rs0, i, planes, -1);
+    fetch(rs0);
+    auto P = [&](int j) { return planes + (j & 1) * RBUF; };
+    for (int it = 0; it < count; it += 3) {
+        __syncthreads();
+        step(P(it), P(it + 1), rs1, it + 1 < count ? -1 : 0);
+        __syncthreads();
+        step(P(it + 1), P(it + 2), rs2, it + 2 < count ? -1 : 0);
+        __syncthreads();
+        step(P(it + 2), P(it + 3), rs0, it + 3 < count ? -1 : 0);
+    }
+
+    const bool atomic_out = g.k_splits > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const long row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            if (col >= g.n) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (r & 3) + 8 * (r >> 2);
+                if (row >= g.m) continue;
+                if (atomic_out) atomicAdd(g.c + row * g.ldc + col, acc[i][j][r]);
+                else g.c[row * g.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+// 1 when lkg_gemm_longk_f32 takes this product (else the caller uses lkg_gemm_f32): long k in whole 16-row tiles,
+// 16-byte aligned rows, widths that are multiples of 4
+extern "C" int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb) {
+    return k >= 8192 && k % RK == 0 && m >= 4 && n >= 4 && m % 4 == 0 && n % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+           lkg_aligned16(a) && lkg_aligned16(b);
+}
+
+extern "C" int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                                  float *c, int64_t ldc, void *stream) {
+    LKG_REQUIRE(m > 0 && n > 0 && k > 0 && a && b && c && ldc >= n && lda >= m && ldb >= n, "lkg_gemm_longk_f32: bad arguments");
+    LKG_REQUIRE(lkg_gemm_longk_ok(m, n, k, a, lda, b, ldb), "lkg_gemm_longk_f32: needs k >= 8192 in whole 16-row tiles, widths and "
+                "row strides that are multiples of 4 floats and 16-byte aligned operands (lkg_gemm_longk_ok)");
+    hipStream_t s = (hipStream_t)stream;
+    WgArgs g{};
+    g.a = a; g.b = b; g.lda = lda; g.ldb = ldb; g.c = c; g.ldc = ldc; g.m = m; g.n = n; g.k = k;
+    g.tiles_m = (int)((m + RM - 1) / RM);
+    g.tiles_n = (int)((n + RN - 1) / RN);
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    LKG_REQUIRE(tiles < 65536, "lkg_gemm_longk_f32: too many tiles");
+    // one workgroup owns a CU: about two rounds of the 256 CUs, at least 64 steps per workgroup
+    int splits = (int)std::max<long>(1, std::min<long>((512 + tiles - 1) / tiles, k / 1024));
+    g.k_splits = splits;
+    if (splits > 1) {
+        const hipError_t rc = ldc == n ? hipMemsetAsync(c, 0, sizeof(float) * m * n, s)
+                                       : hipMemset2DAsync(c, sizeof(float) * ldc, 0, sizeof(float) * n, m, s);
+        if (rc != hipSuccess) {
+            lkg_set_error("lkg_gemm_longk_f32: hipMemsetAsync failed");
+            return LKG_ERR_HIP;
+        }
+    }
+    const int lds = 2 * RBUF * 2;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_longk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            lkg_set_error("lkg_gemm_longk_f32: cannot raise the dynamic LDS limit");
+            return LKG_ERR_HIP;
+        }
+        raised = true;
+    }
+    const long groups = ((long)splits + 7) / 8;
+    hipLaunchKernelGGL(wgrad_longk_kernel, dim3((unsigned)(groups * tiles * 8)), dim3(512), lds, s, g);
+    LKG_CHECK_LAUNCH("lkg_gemm_longk_f32");
+    return LKG_OK;
+}

@@ -144,6 +144,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if not trans_a and k > 0 and tall_ok(m, n, (k,), single_panel_too=tagged_rowmax(a) is not None):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
+    if (trans_a and not trans_b and alpha == 1.0 and beta == 0.0 and bias is None and _WGRAD_ENGINE == "longk"
+            and N.load().lkg_gemm_longk_ok(m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b))):
+        # weight gradients (a^T @ b over millions of rows): the 256 x 128 engine with three tiles in flight
+        N.call("lkg_gemm_longk_f32", m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), N.ptr(out), _ld(out), _stream())
+        return out
     need = int(N.load().lkg_gemm_workspace(int(trans_a), m, n, k)) if _ENGINE != "f32" else 0
     ws = _workspace(need, out.device) if need else None
     N.call("lkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, float(alpha), N.ptr(a), _ld(a), N.ptr(b), _ld(b),
@@ -241,6 +246,7 @@ import os as _os
 
 TALL_MIN_ROWS = 16384          # below this a product is bound by its launch overhead: the f32-MFMA engine serves it
 _ENGINE = _os.environ.get("LKG_GEMM_ENGINE", "f16x2")      # f16x2 | bf16x3 (round-1 split engines) | f32 via lkg_gemm_f32
+_WGRAD_ENGINE = _os.environ.get("LKG_WGRAD_ENGINE", "longk")  # longk (lkg_gemm_longk_f32) | bf16x3 (lkg_gemm_f32's long-k engine)
 _workspaces = {}
 
 
