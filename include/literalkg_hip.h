@@ -375,6 +375,21 @@ int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int64_t ldx, co
                            int64_t ldgo, float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg,
                            float *g_zpre, int64_t ldgz, int32_t activated, float *g_pre_rowmax, void *stream);
 
+/* lkg_gate_blend_bwd_f32 (activated form) with the column statistics of what it reads and writes riding along, so that
+ * the bias and weight gradients that follow need no pass of their own over [g_gpre | g_zpre] (2 d wide) and x:
+ *   stats[0, 2d)         column sums of [g_gpre | g_zpre]        = the bias gradients of g and gate_* (gate.py:24-25)
+ *   stats[2d, 4d)        column maxima |.| of [g_gpre | g_zpre]  }  the column scales of lkg_gemm_wgrad_f32
+ *   stats[4d, 5d)        column maxima |.| of x                  }
+ *   stats[5d + j 2d, ..) sum_r [g_gpre | g_zpre][r, :] * w[r, j] = the weight gradient of a NARROW literal panel w
+ *                        (n_w <= 4 columns, nullable: the numeric literals, gate.py:23)
+ * d a multiple of 4, <= 1024, 16-byte aligned operands.  workspace: 1024 (5 + 2 n_w) d floats (per-workgroup partial
+ * vectors folded by a second tiny launch: no float atomics, the statistics are deterministic).                   */
+int lkg_gate_blend_bwd_stats_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre, int64_t ldg,
+                                 const float *zpre, int64_t ldz, const float *g_out, int64_t ldgo, float *g_x,
+                                 int64_t ldgx, float *g_gpre, int64_t ldgg, float *g_zpre, int64_t ldgz,
+                                 int32_t activated, float *g_pre_rowmax, const float *w, int64_t ldw, int32_t n_w,
+                                 float *workspace, int64_t workspace_floats, float *stats, void *stream);
+
 /* Weight-gradient product on the fp16 matrix cores (lkg_gemm_wgrad.hip):  C[m, n] = sum over the k rows of
  * A[k, m] * B[k, n]  (both operands k-major: dW = dY^T X of nn.Linear with k = rows, model.py:93-149, gate.py:22-25),
  * f32 in / f32 out, C overwritten.  a_colmax / b_colmax (device float[m] / float[n]): max |A[:, j]| / max |B[:, j]| --

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "lkg_relu_batchnorm_bwd_f32": [i64, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp],
     "lkg_gate_blend_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gate_blend_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, vp],
+    "lkg_gate_blend_bwd_stats_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, vp,
+                                     i64, i32, vp, i64, vp, vp],
     "lkg_row_absmax_f32": [i64, i32, vp, i64, vp, i32, vp],
     "lkg_gemm_tall_workspace": [i32, i32, vp, i32],
     "lkg_gemm_tall_f32": [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, i64, vp, i32, vp, i64, vp, i64,

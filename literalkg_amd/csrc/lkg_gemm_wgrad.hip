@@ -257,12 +257,18 @@ extern "C" int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t 
     return LKG_OK;
 }
 
+extern "C" int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
+static int longk_launch(bool f16, int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
+                        const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc, hipStream_t s);
+
 extern "C" int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
                                   const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc,
                                   void *stream) {
     LKG_REQUIRE(m >= 0 && n >= 0 && k >= 0, "lkg_gemm_wgrad_f32: negative size");
     if (m == 0 || n == 0) return LKG_OK;
     LKG_REQUIRE(c && ldc >= n, "lkg_gemm_wgrad_f32: bad C (ldc=%lld, n=%lld)", (long long)ldc, (long long)n);
+    if (a && b && a_colmax && b_colmax && lda >= m && ldb >= n && lkg_gemm_longk_ok(m, n, k, a, lda, b, ldb))
+        return longk_launch(true, m, n, k, a, lda, a_colmax, b, ldb, b_colmax, c, ldc, (hipStream_t)stream);   // 256 x 128 tiles, 3 tiles in flight
     hipStream_t s = (hipStream_t)stream;
     WgArgs g{};
     g.a = a; g.b = b; g.lda = lda; g.ldb = ldb; g.a_colmax = a_colmax; g.b_colmax = b_colmax; g.c = c; g.ldc = ldc;
@@ -496,6 +502,160 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
+// The f16 x 2 arithmetic of wgrad_f16x2_kernel (column scales, exact hi / mid split, 12 MFMAs per step instead of 24) in the
+// structure of wgrad_longk_kernel: with half the MFMAs the step is bound by its 24 KB of loads, three tiles in flight.
+namespace {
+constexpr int HBUF = 2 * (RA_PLANE + RB_PLANE);                        // fp16 elements per plane buffer (24 KB)
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_longk_f16_kernel(WgArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char longk_smem[];
+    _Float16 *planes = reinterpret_cast<_Float16 *>(longk_smem);                 // [2][A hi mid | B hi mid]
+    typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+    if (split >= g.k_splits) return;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const long m0 = (long)tm * RM, n0 = (long)tn * RN;
+    const long per = ((g.k + g.k_splits - 1) / g.k_splits + RK - 1) / RK * RK;
+    const long k_lo = (long)split * per, k_hi = min(g.k, k_lo + per);
+    if (k_lo >= k_hi) return;
+    const int count = (int)((k_hi - k_lo) / RK);
+
+    const int ka = t >> 6, ca = 4 * (t & 63), kb = t >> 5, cb = 4 * (t & 31);
+    const int keep_a = (m0 + ca + 3 < g.m) ? -1 : 0, keep_b = (n0 + cb + 3 < g.n) ? -1 : 0;
+    const float *pa0 = g.a + (k_lo + ka) * g.lda + min(m0 + ca, g.m - 4);
+    const float *pa1 = pa0 + 8 * g.lda;
+    const float *pb = g.b + (k_lo + kb) * g.ldb + min(n0 + cb, g.n - 4);
+    const long step_a = RK * g.lda, step_b = RK * g.ldb;
+    float sa[4], sb[4];                           // 2^e of this thread's columns (both A pieces share theirs)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sa[j] = ldexpf(1.f, scale_exponent(g.a_colmax[min(m0 + ca + j, g.m - 1)]));
+        sb[j] = ldexpf(1.f, scale_exponent(g.b_colmax[min(n0 + cb + j, g.n - 1)]));
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rs0[3], rs1[3], rs2[3];
+    int fetched = 0;
+    auto fetch = [&](f32x4 (&r)[3]) {
+        r[0] = *reinterpret_cast<const f32x4 *>(pa0);
+        r[1] = *reinterpret_cast<const f32x4 *>(pa1);
+        r[2] = *reinterpret_cast<const f32x4 *>(pb);
+        ++fetched;
+        const bool more = fetched < count;
+        pa0 += more ? step_a : 0;
+        pa1 += more ? step_a : 0;
+        pb += more ? step_b : 0;
+    };
+    float px[6][2];
+    fp16x2 ph[6], pm[6];
+    auto t1 = [&](const f32x4 (&r)[3], int q, int live) {      // pair q: piece q >> 1, elements 2 (q & 1), 2 (q & 1) + 1
+        const f32x4 v = r[q >> 1];
+        const bool isb = (q >> 1) == 2;
+        const int keep = (isb ? keep_b : keep_a) & live, e0 = 2 * (q & 1);
+        px[q][0] = __int_as_float(__float_as_int(v[e0]) & keep) * (isb ? sb[e0] : sa[e0]);
+        px[q][1] = __int_as_float(__float_as_int(v[e0 + 1]) & keep) * (isb ? sb[e0 + 1] : sa[e0 + 1]);
+        ph[q] = __builtin_amdgcn_cvt_pkrtz(px[q][0], px[q][1]);
+    };
+    auto t2 = [&](int q) {
+        pm[q] = __builtin_amdgcn_cvt_pkrtz((px[q][0] - (float)ph[q][0]) * 2048.f, (px[q][1] - (float)ph[q][1]) * 2048.f);
+    };
+    const int off_a0 = roff<RM>(ka, ca), off_a1 = roff<RM>(ka + 8, ca), off_b = roff<RN>(kb, cb);
+    auto write_piece = [&](int p, _Float16 *D) {
+        _Float16 *plane0 = p == 2 ? D + 2 * RA_PLANE : D;
+        const int pe = p == 2 ? RB_PLANE : RA_PLANE, off = p == 0 ? off_a0 : (p == 1 ? off_a1 : off_b);
+        const fp16x4 h = {ph[2 * p][0], ph[2 * p][1], ph[2 * p + 1][0], ph[2 * p + 1][1]};
+        const fp16x4 m = {pm[2 * p][0], pm[2 * p][1], pm[2 * p + 1][0], pm[2 * p + 1][1]};
+        *reinterpret_cast<fp16x4 *>(plane0 + off) = h;
+        *reinterpret_cast<fp16x4 *>(plane0 + pe + off) = m;
+    };
+#define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
+#define LKG_MF(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
+    auto hfrag = [&](const _Float16 *plane, int cols, int c0) {
+        return cols == RM ? __builtin_bit_cast(f16x8, rfrag<RM>(reinterpret_cast<const __bf16 *>(plane), c0, lane))
+                          : __builtin_bit_cast(f16x8, rfrag<RN>(reinterpret_cast<const __bf16 *>(plane), c0, lane));
+    };
+    // the 12 MFMAs of the tile in S with the split of the next tile (register set r -> D) and the 2^-11 copies of the hi
+    // fragments sliced between them
+    auto step = [&](const _Float16 *S, _Float16 *D, f32x4 (&r)[3], int live) {
+        const _Float16 *SA = S, *SB = S + 2 * RA_PLANE;
+        f16x8 ah[2], am[2], bh[2], bm[2], ahs[2], bhs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = hfrag(SA, RM, wm * 64 + i * 32);
+            bh[i] = hfrag(SB, RN, wn * 64 + i * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bm[i] = hfrag(SB + RB_PLANE, RN, wn * 64 + i * 32);
+            am[i] = hfrag(SA + RA_PLANE, RM, wm * 64 + i * 32);
+        }
+        const _Float16 sc = (_Float16)(1.f / 2048.f);
+        LKG_PIN();
+        LKG_MF(acc[0][0], ah[0], bh[0]); ahs[0] = ah[0] * sc; t1(r, 0, live); LKG_PIN();
+        LKG_MF(acc[0][1], ah[0], bh[1]); ahs[1] = ah[1] * sc; t1(r, 1, live); LKG_PIN();
+        LKG_MF(acc[1][0], ah[1], bh[0]); t1(r, 2, live); t1(r, 3, live); LKG_PIN();
+        LKG_MF(acc[1][1], ah[1], bh[1]); t1(r, 4, live); t1(r, 5, live); LKG_PIN();
+        LKG_MF(acc[0][0], ahs[0], bm[0]); bhs[0] = bh[0] * sc; t2(0); LKG_PIN();
+        LKG_MF(acc[0][1], ahs[0], bm[1]); bhs[1] = bh[1] * sc; t2(1); LKG_PIN();
+        LKG_MF(acc[1][0], ahs[1], bm[0]); t2(2); write_piece(0, D); LKG_PIN();
+        LKG_MF(acc[1][1], ahs[1], bm[1]); t2(3); LKG_PIN();
+        LKG_MF(acc[0][0], am[0], bhs[0]); t2(4); write_piece(1, D); LKG_PIN();
+        LKG_MF(acc[0][1], am[0], bhs[1]); t2(5); LKG_PIN();
+        LKG_MF(acc[1][0], am[1], bhs[0]); write_piece(2, D); LKG_PIN();
+        LKG_MF(acc[1][1], am[1], bhs[1]); fetch(r);
+    };
+#undef LKG_MF
+#undef LKG_PIN
+
+    fetch(rs0);
+    fetch(rs1);
+    fetch(rs2);
+    for (int q = 0; q < 6; ++q) { t1(rs0, q, -1); t2(q); }
+    for (int p = 0; p < 3; ++p) write_piece(p, planes);
+    fetch(rs0);
+    auto P = [&](int j) { return planes + (j & 1) * HBUF; };
+    for (int it = 0; it < count; it += 3) {
+        __syncthreads();
+        step(P(it), P(it + 1), rs1, it + 1 < count ? -1 : 0);
+        __syncthreads();
+        step(P(it + 1), P(it + 2), rs2, it + 2 < count ? -1 : 0);
+        __syncthreads();
+        step(P(it + 2), P(it + 3), rs0, it + 3 < count ? -1 : 0);
+    }
+
+    const bool atomic_out = g.k_splits > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const long row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            if (col >= g.n) continue;
+            const int ecol = scale_exponent(g.b_colmax[col]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (r & 3) + 8 * (r >> 2);
+                if (row >= g.m) continue;
+                const float v = ldexpf(acc[i][j][r], -(scale_exponent(g.a_colmax[row]) + ecol));
+                if (atomic_out) atomicAdd(g.c + row * g.ldc + col, v);
+                else g.c[row * g.ldc + col] = v;
+            }
+        }
+}
+}  // namespace
+
 // 1 when lkg_gemm_longk_f32 takes this product (else the caller uses lkg_gemm_f32): long k in whole 16-row tiles,
 // 16-byte aligned rows, widths that are multiples of 4
 extern "C" int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb) {
@@ -503,14 +663,11 @@ extern "C" int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a
            lkg_aligned16(a) && lkg_aligned16(b);
 }
 
-extern "C" int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
-                                  float *c, int64_t ldc, void *stream) {
-    LKG_REQUIRE(m > 0 && n > 0 && k > 0 && a && b && c && ldc >= n && lda >= m && ldb >= n, "lkg_gemm_longk_f32: bad arguments");
-    LKG_REQUIRE(lkg_gemm_longk_ok(m, n, k, a, lda, b, ldb), "lkg_gemm_longk_f32: needs k >= 8192 in whole 16-row tiles, widths and "
-                "row strides that are multiples of 4 floats and 16-byte aligned operands (lkg_gemm_longk_ok)");
-    hipStream_t s = (hipStream_t)stream;
+static int longk_launch(bool f16, int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *a_colmax,
+                        const float *b, int64_t ldb, const float *b_colmax, float *c, int64_t ldc, hipStream_t s) {
     WgArgs g{};
-    g.a = a; g.b = b; g.lda = lda; g.ldb = ldb; g.c = c; g.ldc = ldc; g.m = m; g.n = n; g.k = k;
+    g.a = a; g.b = b; g.lda = lda; g.ldb = ldb; g.a_colmax = a_colmax; g.b_colmax = b_colmax; g.c = c; g.ldc = ldc;
+    g.m = m; g.n = n; g.k = k;
     g.tiles_m = (int)((m + RM - 1) / RM);
     g.tiles_n = (int)((n + RN - 1) / RN);
     const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -526,18 +683,27 @@ extern "C" int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *
             return LKG_ERR_HIP;
         }
     }
-    const int lds = 2 * RBUF * 2;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_longk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
+    const int lds = (f16 ? HBUF : RBUF) * 2 * 2;
+    static bool raised[2] = {false, false};
+    if (!raised[f16]) {
+        const void *fn = f16 ? reinterpret_cast<const void *>(wgrad_longk_f16_kernel) : reinterpret_cast<const void *>(wgrad_longk_kernel);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             lkg_set_error("lkg_gemm_longk_f32: cannot raise the dynamic LDS limit");
             return LKG_ERR_HIP;
         }
-        raised = true;
+        raised[f16] = true;
     }
     const long groups = ((long)splits + 7) / 8;
-    hipLaunchKernelGGL(wgrad_longk_kernel, dim3((unsigned)(groups * tiles * 8)), dim3(512), lds, s, g);
+    if (f16) hipLaunchKernelGGL(wgrad_longk_f16_kernel, dim3((unsigned)(groups * tiles * 8)), dim3(512), lds, s, g);
+    else hipLaunchKernelGGL(wgrad_longk_kernel, dim3((unsigned)(groups * tiles * 8)), dim3(512), lds, s, g);
     LKG_CHECK_LAUNCH("lkg_gemm_longk_f32");
     return LKG_OK;
+}
+
+extern "C" int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                                  float *c, int64_t ldc, void *stream) {
+    LKG_REQUIRE(m > 0 && n > 0 && k > 0 && a && b && c && ldc >= n && lda >= m && ldb >= n, "lkg_gemm_longk_f32: bad arguments");
+    LKG_REQUIRE(lkg_gemm_longk_ok(m, n, k, a, lda, b, ldb), "lkg_gemm_longk_f32: needs k >= 8192 in whole 16-row tiles, widths and "
+                "row strides that are multiples of 4 floats and 16-byte aligned operands (lkg_gemm_longk_ok)");
+    return longk_launch(false, m, n, k, a, lda, nullptr, b, ldb, nullptr, c, ldc, (hipStream_t)stream);
 }

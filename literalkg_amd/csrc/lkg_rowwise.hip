@@ -343,6 +343,144 @@ __global__ __launch_bounds__(256) void gate_blend_bwd_kernel(long n, int d, int 
     }
 }
 
+// The same backward with the column statistics of what it reads and writes riding along, so that the weight / bias
+// gradients that follow need no pass of their own over [g_gpre | g_zpre] (2 d wide) and x:
+//   stats[0, 2d)        column sums of [g_gpre | g_zpre]          = the bias gradients of g and gate_*  (gate.py:24-25)
+//   stats[2d, 4d)       column maxima |.| of [g_gpre | g_zpre]    } the column scales of the fp16 weight-gradient product
+//   stats[4d, 5d)       column maxima |.| of x                    }   (lkg_gemm_wgrad_f32)
+//   stats[5d + j 2d ..) sum_r [g_gpre | g_zpre][r, :] * w[r, j]    = the weight gradients of a NARROW literal panel w
+//                                                                   (n_w <= 4 columns: the numeric literals)
+// 16-byte path, one column chunk per thread (d <= 1024).  At most STAT_BLOCKS workgroups: every thread keeps running
+// sums / maxima of its four columns over its rows, the block's row groups meet in LDS, the block writes ONE partial
+// vector, and gate_stats_finish_kernel folds the partials (no atomics: deterministic).
+constexpr int STAT_BLOCKS = 1024;
+template <int NW>
+__global__ __launch_bounds__(256) void gate_blend_bwd_stats_kernel(long n, int d, int log_tpr, const float *__restrict__ x,
+                                                                    long ldx, const float *__restrict__ gpre, long ldg,
+                                                                    const float *__restrict__ zpre, long ldz,
+                                                                    const float *__restrict__ g_out, long ldgo,
+                                                                    float *__restrict__ g_x, long ldgx,
+                                                                    float *__restrict__ g_gpre, long ldgg,
+                                                                    float *__restrict__ g_zpre, long ldgz, int activated,
+                                                                    int *__restrict__ pre_rowmax,
+                                                                    const float *__restrict__ w, long ldw,
+                                                                    float *__restrict__ partial) {
+    constexpr int W = 4, NV = 5 + 2 * NW;          // per column: sum og, sum oz, max og, max oz, max x, NW x (w og, w oz)
+    __shared__ float red[NV][256][W];
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c = (threadIdx.x & (tpr - 1)) * W;
+    const bool has_col = c < d;
+    float acc[NV][W];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[v][k] = 0.f;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb) {
+        float rmax = 0.f;
+        if (has_col) {
+            float xv[W], gv[W], zv[W], go[W], ox[W], og[W], oz[W], wv[NW > 0 ? NW : 1];
+            *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+            *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(gpre + r * ldg + c);
+            *reinterpret_cast<float4 *>(zv) = *reinterpret_cast<const float4 *>(zpre + r * ldz + c);
+            *reinterpret_cast<float4 *>(go) = *reinterpret_cast<const float4 *>(g_out + r * ldgo + c);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wv[j] = w[r * ldw + j];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float s = activated ? zv[k] : sigmoid_fast(zv[k]);
+                const float tg = activated ? gv[k] : tanh_fast(gv[k]);
+                ox[k] = go[k] * (1.f - s);
+                og[k] = go[k] * s * (1.f - tg * tg);
+                oz[k] = go[k] * (tg - xv[k]) * s * (1.f - s);
+                rmax = fmaxf(rmax, fmaxf(fabsf(og[k]), fabsf(oz[k])));
+                acc[0][k] += og[k];
+                acc[1][k] += oz[k];
+                acc[2][k] = fmaxf(acc[2][k], fabsf(og[k]));
+                acc[3][k] = fmaxf(acc[3][k], fabsf(oz[k]));
+                acc[4][k] = fmaxf(acc[4][k], fabsf(xv[k]));
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    acc[5 + 2 * j][k] = fmaf(og[k], wv[j], acc[5 + 2 * j][k]);
+                    acc[6 + 2 * j][k] = fmaf(oz[k], wv[j], acc[6 + 2 * j][k]);
+                }
+            }
+            *reinterpret_cast<float4 *>(g_x + r * ldgx + c) = *reinterpret_cast<float4 *>(ox);
+            *reinterpret_cast<float4 *>(g_gpre + r * ldgg + c) = *reinterpret_cast<float4 *>(og);
+            *reinterpret_cast<float4 *>(g_zpre + r * ldgz + c) = *reinterpret_cast<float4 *>(oz);
+        }
+        if (pre_rowmax) {
+            const int span = tpr < 64 ? tpr : 64;
+            for (int m = 1; m < span; m <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, m, 64));
+            if ((threadIdx.x & (span - 1)) == 0) atomicMax(pre_rowmax + r, __float_as_int(rmax));
+        }
+    }
+    // the rpb row groups of the block hold the same columns: fold them, then one partial vector per block
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < W; ++k) red[v][threadIdx.x][k] = acc[v][k];
+    __syncthreads();
+    if (threadIdx.x < tpr && has_col) {
+        const int two_d = 2 * d;
+        float *pb = partial + (long)blockIdx.x * ((5 + 2 * NW) * d);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float f[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float a = red[v][threadIdx.x][k];
+                for (int g = 1; g < rpb; ++g) {
+                    const float b = red[v][threadIdx.x + g * tpr][k];
+                    a = (v >= 2 && v <= 4) ? fmaxf(a, b) : a + b;
+                }
+                f[v] = a;
+            }
+            const int col = c + k;
+            pb[col] = f[0];                 // sums: og | oz
+            pb[d + col] = f[1];
+            pb[two_d + col] = f[2];         // maxima: og | oz
+            pb[two_d + d + col] = f[3];
+            pb[2 * two_d + col] = f[4];     // maxima of x
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                pb[5 * d + j * two_d + col] = f[5 + 2 * j];
+                pb[5 * d + j * two_d + d + col] = f[6 + 2 * j];
+            }
+        }
+    }
+}
+
+// stats[i] = fold over the blocks' partial vectors: maxima for i in [2d, 5d), sums elsewhere.  64 statistics per
+// workgroup, four threads each (interleaved blocks, eight loads in flight), folded in LDS in a fixed order.
+__global__ __launch_bounds__(256) void gate_stats_finish_kernel(int n_stats, int d, int n_blocks, const float *__restrict__ partial,
+                                                                float *__restrict__ stats) {
+    __shared__ float red[4][64];
+    const int q = threadIdx.x >> 6, i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool live = i < n_stats, is_max = i >= 2 * d && i < 5 * d;
+    float a = 0.f;
+    if (live) {
+        int b = q;
+        for (; b + 28 < n_blocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + 4 * u) * n_stats + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = is_max ? fmaxf(a, v[u]) : a + v[u];
+        }
+        for (; b < n_blocks; b += 4) {
+            const float v = partial[(long)b * n_stats + i];
+            a = is_max ? fmaxf(a, v) : a + v;
+        }
+    }
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && live) {
+        const int l = threadIdx.x;
+        stats[i] = is_max ? fmaxf(fmaxf(red[0][l], red[1][l]), fmaxf(red[2][l], red[3][l]))
+                          : (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+
 // threads per row (log2) for a row of `units` access units
 inline int log_threads_per_row(int units) {
     int l = 0;
@@ -478,6 +616,48 @@ extern "C" int lkg_gate_blend_bwd_f32(int64_t n, int32_t d, const float *x, int6
                            d, lt, x, (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx,
                            g_gpre, (long)ldgg, g_zpre, (long)ldgz, activated, reinterpret_cast<int *>(g_pre_rowmax));
     LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_f32");
+    return LKG_OK;
+}
+
+// The backward of the blend with the column statistics of [g_gpre | g_zpre] and x riding along (see
+// gate_blend_bwd_stats_kernel): stats has (5 + 2 n_w) d floats, workspace STAT_BLOCKS = 1024 times that.
+extern "C" int lkg_gate_blend_bwd_stats_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *gpre,
+                                            int64_t ldg, const float *zpre, int64_t ldz, const float *g_out, int64_t ldgo,
+                                            float *g_x, int64_t ldgx, float *g_gpre, int64_t ldgg, float *g_zpre,
+                                            int64_t ldgz, int32_t activated, float *g_pre_rowmax, const float *w,
+                                            int64_t ldw, int32_t n_w, float *workspace, int64_t workspace_floats,
+                                            float *stats, void *stream) {
+    LKG_REQUIRE(n > 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx >= d && ldg >= d && ldz >= d && ldgo >= d && ldgx >= d &&
+                    ldgg >= d && ldgz >= d, "lkg_gate_blend_bwd_stats_f32: bad sizes (d a multiple of 4, <= 1024)");
+    LKG_REQUIRE(n_w >= 0 && n_w <= 4 && (n_w == 0 || (w && ldw >= n_w)), "lkg_gate_blend_bwd_stats_f32: narrow panel of 0..4 columns");
+    LKG_REQUIRE(x && gpre && zpre && g_out && g_x && g_gpre && g_zpre && workspace && stats, "lkg_gate_blend_bwd_stats_f32: null pointer");
+    const bool vec = ldx % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldgo % 4 == 0 && ldgx % 4 == 0 && ldgg % 4 == 0 &&
+                     ldgz % 4 == 0 && lkg_aligned16(x) && lkg_aligned16(gpre) && lkg_aligned16(zpre) && lkg_aligned16(g_out) &&
+                     lkg_aligned16(g_x) && lkg_aligned16(g_gpre) && lkg_aligned16(g_zpre);
+    LKG_REQUIRE(vec, "lkg_gate_blend_bwd_stats_f32: operands must be 16-byte aligned with row strides that are multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    if (g_pre_rowmax && hipMemsetAsync(g_pre_rowmax, 0, sizeof(float) * n, s) != hipSuccess) {
+        lkg_set_error("lkg_gate_blend_bwd_stats_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    const int lt = log_threads_per_row(d / 4), rpb = 256 >> lt;
+    const int n_stats = (5 + 2 * n_w) * d;
+    const int blocks = (int)std::min<int64_t>((n + rpb - 1) / rpb, STAT_BLOCKS);
+    LKG_REQUIRE(workspace_floats >= (int64_t)blocks * n_stats, "lkg_gate_blend_bwd_stats_f32: workspace of %lld floats, %lld needed",
+                (long long)workspace_floats, (long long)blocks * n_stats);
+#define LKG_GBS(NW)                                                                                                       \
+    case NW:                                                                                                              \
+        hipLaunchKernelGGL(gate_blend_bwd_stats_kernel<NW>, dim3((unsigned)blocks), dim3(256), 0, s, (long)n, d, lt, x,  \
+                           (long)ldx, gpre, (long)ldg, zpre, (long)ldz, g_out, (long)ldgo, g_x, (long)ldgx, g_gpre,      \
+                           (long)ldgg, g_zpre, (long)ldgz, activated, reinterpret_cast<int *>(g_pre_rowmax), w,          \
+                           (long)ldw, workspace);                                                                        \
+        break;
+    switch (n_w) { LKG_GBS(0) LKG_GBS(1) LKG_GBS(2) LKG_GBS(3) LKG_GBS(4) }
+#undef LKG_GBS
+    LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_stats_f32");
+    hipLaunchKernelGGL(gate_stats_finish_kernel, dim3((unsigned)((n_stats + 63) / 64)), dim3(256), 0, s, n_stats, d, blocks,
+                       workspace, stats);
+    LKG_CHECK_LAUNCH("lkg_gate_blend_bwd_stats_f32");
     return LKG_OK;
 }
 

@@ -980,6 +980,9 @@ class _FusedGate(Function):
         ctx.has_bias = bg is not None
         if training:
             ctx.save_for_backward(x, keep[0], keep[1], *panels[1:], *wgs, *wzs)
+            # column maxima of the (constant) wide literal tables, once per table: column scales of their weight gradient
+            ctx.lit_colmax = [tagged_colmax(l, cache=True) if (l.shape[1] > 4 and n >= TALL_MIN_ROWS) else None
+                              for l in panels[1:]]
         return out
 
     @staticmethod
@@ -996,8 +999,28 @@ class _FusedGate(Function):
         need = ctx.needs_input_grad           # (out, bg, bz, n_lit, grad_mode, x, lits..., wgs..., wzs...)
         tall = need[5] and tall_ok(n, d, (d, d))
         rm = torch.empty(n, dtype=torch.float32, device=x.device) if tall else None   # row scale of the data-gradient GEMM
-        N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
-               _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, N.ptr(rm), _stream())
+        panels = (x,) + tuple(lits)
+        base = 6 + nl
+        want = [need[base + i] or need[base + nl + 1 + i] for i in range(nl + 1)]
+        want_bias = ctx.has_bias and (need[1] or need[2])
+        # the blend kernel can emit, while it writes [g_gpre | g_zpre], everything the weight / bias gradients need beside the
+        # wide products: the bias sums, ONE narrow literal panel's weight gradient (the numeric literals), and the column
+        # maxima of [g_gpre | g_zpre] and of x -- the column scales of the fp16 long-k product (lkg_gemm_wgrad_f32)
+        narrow = [i for i in range(1, nl + 1) if want[i] and panels[i].shape[1] <= 4]
+        stats = None
+        if (_WGRAD_ENGINE == "longk" and n >= TALL_MIN_ROWS and d % 4 == 0 and d <= 1024 and len(narrow) <= 1
+                and all(t_.data_ptr() % 16 == 0 and _ld(t_) % 4 == 0 for t_ in (x, g, z, go))):
+            wn = _f32_rows(panels[narrow[0]]) if narrow else None
+            n_w = wn.shape[1] if wn is not None else 0
+            n_stats = (5 + 2 * n_w) * d
+            ws = _workspace(4 * 1024 * n_stats, x.device).view(torch.float32)
+            stats = torch.empty(n_stats, dtype=torch.float32, device=x.device)
+            N.call("lkg_gate_blend_bwd_stats_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
+                   _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, N.ptr(rm), N.ptr(wn),
+                   _ld(wn) if wn is not None else 0, n_w, N.ptr(ws), ws.numel(), N.ptr(stats), _stream())
+        else:
+            N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), _ld(x), N.ptr(g), _ld(g), N.ptr(z), _ld(z), N.ptr(go),
+                   _ld(go), N.ptr(gx), _ld(gx), N.ptr(ggp), _ld(ggp), N.ptr(gzp), _ld(gzp), 1, N.ptr(rm), _stream())
         g_x = None
         if need[5]:
             if tall:
@@ -1007,10 +1030,20 @@ class _FusedGate(Function):
                 g_x = gemm(gzp, wzs[0], beta=1.0, out=g_x)
         # weight and bias gradients of both projections from the side-by-side buffer: [g_gpre | g_zpre]^T @ panel is
         # [2d x k]: rows :d are g's, rows d: gate_*'s (one long-k product per panel reads the panel once)
-        panels = (x,) + tuple(lits)
-        base = 6 + nl
-        want = [need[base + i] or need[base + nl + 1 + i] for i in range(nl + 1)]
-        gws, gb = weight_grads(gpz, panels, want, ctx.has_bias and (need[1] or need[2]))
+        if stats is not None:
+            gb = stats[:2 * d] if want_bias else None
+            cm_g, cm_x = stats[2 * d:4 * d], stats[4 * d:5 * d]
+            gws = [None] * (nl + 1)
+            for i in range(nl + 1):
+                if not want[i]:
+                    continue
+                if narrow and i == narrow[0]:
+                    gws[i] = stats[5 * d:].view(n_w, 2 * d).t()          # [2d x n_w]
+                    continue
+                cm_p = cm_x if i == 0 else ctx.lit_colmax[i - 1]        # (the literal tables are constants: cached in forward)
+                gws[i] = gemm_wgrad(gpz, panels[i], cm_g, cm_p) if cm_p is not None else gemm(gpz, panels[i], trans_a=True)
+        else:
+            gws, gb = weight_grads(gpz, panels, want, want_bias)
         g_wg = [gws[i][:d] if need[base + i] else None for i in range(nl + 1)]
         g_wz = [gws[i][d:] if need[base + nl + 1 + i] else None for i in range(nl + 1)]
         gb_g = gb[:d] if (gb is not None and need[1]) else None

@@ -1591,3 +1591,42 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
         scale = float(want[k].abs().max()) + 1e-30
         assert float((got[k] - want[k]).abs().max()) <= 5e-5 * scale, k
     ops._RowScratch._tables.clear()
+
+
+@pytest.mark.parametrize("d,n_w", [(64, 2), (256, 0), (100, 1), (512, 4)])
+def test_gate_backward_statistics_ride_along(ops, gpu_device, d, n_w):
+    """lkg_gate_blend_bwd_stats_f32: the same three outputs as lkg_gate_blend_bwd_f32, and its column statistics (bias
+    sums, column maxima of [g_gpre | g_zpre] and of x, the narrow panel's weight gradient) against torch in f64."""
+    from literalkg_amd import _native as N
+    torch.manual_seed(d)
+    n = 7001
+    x, gt, zs, go = (torch.randn(n, d, device=gpu_device) for _ in range(4))
+    gt, zs = torch.tanh(gt), torch.sigmoid(zs)
+    w = torch.rand(n, max(n_w, 1), device=gpu_device)
+    outs = []
+    for stats_mode in (False, True):
+        gx = torch.empty(n, d, device=gpu_device)
+        gpz = torch.empty(n, 2 * d, device=gpu_device)
+        rm = torch.empty(n, device=gpu_device)
+        if stats_mode:
+            n_stats = (5 + 2 * n_w) * d
+            ws = torch.empty(1024 * n_stats, device=gpu_device)
+            st = torch.empty(n_stats, device=gpu_device)
+            N.call("lkg_gate_blend_bwd_stats_f32", n, d, N.ptr(x), d, N.ptr(gt), d, N.ptr(zs), d, N.ptr(go), d, N.ptr(gx), d,
+                   N.ptr(gpz), 2 * d, gpz.data_ptr() + 4 * d, 2 * d, 1, N.ptr(rm), N.ptr(w) if n_w else None, w.shape[1], n_w,
+                   N.ptr(ws), ws.numel(), N.ptr(st), None)
+        else:
+            N.call("lkg_gate_blend_bwd_f32", n, d, N.ptr(x), d, N.ptr(gt), d, N.ptr(zs), d, N.ptr(go), d, N.ptr(gx), d,
+                   N.ptr(gpz), 2 * d, gpz.data_ptr() + 4 * d, 2 * d, 1, N.ptr(rm), None)
+        outs.append((gx, gpz, rm))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    gpz64 = outs[0][1].double()
+    tol = lambda ref: 2e-6 * float(ref.abs().max()) + 1e-30
+    assert float((st[:2 * d].double() - gpz64.sum(0)).abs().max()) <= 2e-6 * float(gpz64.abs().sum(0).max())
+    assert torch.equal(st[2 * d:4 * d], outs[0][1].abs().amax(0))
+    assert torch.equal(st[4 * d:5 * d], x.abs().amax(0))
+    if n_w:
+        want = (gpz64.t() @ w[:, :n_w].double())                       # [2d x n_w]
+        got = st[5 * d:].view(n_w, 2 * d).t().double()
+        assert float((got - want).abs().max()) <= 2e-6 * float((gpz64.abs().t() @ w[:, :n_w].double()).max())
