@@ -336,7 +336,11 @@ def rows_worth_compacting(rows: Optional[RowSet], n: int) -> bool:
     return rows is not None and n >= TALL_MIN_ROWS and rows.n_max * 8 <= n
 
 
+_HAS_USE_COUNT = hasattr(torch._C, "_storage_Use_Count")
+
+
 def _storage_users(t: torch.Tensor) -> int:
+    """How many tensors / views share t's storage (a private torch hook; without it the kept-zero tables are not used)."""
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
 
 
@@ -388,7 +392,7 @@ class _RowScratch:
 
 def _loss_grad_table(emb: torch.Tensor, sparse_rows: bool, *id_lists: torch.Tensor) -> torch.Tensor:
     """The all-zero N x C table a loss backward scatters its rows ``id_lists`` (int64, contiguous) into."""
-    if not sparse_rows:
+    if not sparse_rows or not _HAS_USE_COUNT:
         return torch.zeros_like(emb, memory_format=torch.contiguous_format)
     ent = _RowScratch.acquire(emb.shape[0], emb.shape[1], emb.device)
     ent.mark(*id_lists)
