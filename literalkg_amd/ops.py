@@ -363,6 +363,7 @@ class _RowScratch:
         self.flags = torch.zeros(shape[0], dtype=torch.uint8, device=device) if with_flags else None
         self.users = _storage_users(self.buf)
         self.dirty: list = []
+        self.unknown = False          # rows were written that ``dirty`` does not list yet (a backward died in between)
 
     @classmethod
     def acquire(cls, n: int, c: int, device, pool: str = "loss") -> "_RowScratch":
@@ -373,9 +374,15 @@ class _RowScratch:
         cls._tables[key] = ent                       # (most recently used last)
         while len(cls._tables) > cls.MAX_TABLES:     # another model / shape: let the oldest table go
             cls._tables.pop(next(iter(cls._tables)))
-        for ids in ent.dirty:
-            N.call("lkg_fill_rows_f32", ids.numel(), ent.buf.shape[1], N.ptr(ids), N.ptr(ent.buf), _ld(ent.buf), 0.0,
-                   N.ptr(ent.flags), 0, _stream())
+        if ent.unknown:               # (only after an exception between a kernel's writes and their book-keeping)
+            ent.buf.zero_()
+            if ent.flags is not None:
+                ent.flags.zero_()
+            ent.unknown = False
+        else:
+            for ids in ent.dirty:
+                N.call("lkg_fill_rows_f32", ids.numel(), ent.buf.shape[1], N.ptr(ids), N.ptr(ent.buf), _ld(ent.buf), 0.0,
+                       N.ptr(ent.flags), 0, _stream())
         ent.dirty = []
         return ent
 
@@ -575,10 +582,12 @@ class _Aggregate(Function):
             ent = _RowScratch.acquire(g.n, d, grad.device, "g_agg")
             out = ent.buf.view(ent.buf.shape)
             reached = torch.empty(g.n, dtype=torch.uint8, device=grad.device)
+            ent.unknown = True            # (until the rows the kernel writes are on record)
             spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, out=out, long_rows=g.long_rows(True),
                      add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows, out_rows=reached)
             ids = torch.nonzero(reached).flatten()
             ent.dirty.append(ids)
+            ent.unknown = False
             return tag_rows(out, RowSet(reached, [ids], unique=True)), None, None, None, None
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True),
                         add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows), None, None, None, None
