@@ -335,14 +335,17 @@ int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, int32_t n_se
  * save_mean / save_rstd float[n] are kept for the backward.
  * drop_p > 0: message dropout (nn.Dropout, model.py:28/161) is applied to y BEFORE the normalised
  *   copy is taken, y *= keep(seed, row*d + col) / (1 - drop_p) with a counter-based mask that the
- *   backward regenerates from the same seed.                                           */
+ *   backward regenerates from the same seed.
+ * y may be NULL (with yn given): the last layer's un-normalised output is read by nobody.   */
 int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
                               const float *gamma, const float *beta, float eps, float *y,
                               int64_t ldy, float *yn, int64_t ldyn, float norm_eps,
                               float *save_mean, float *save_rstd, float drop_p, uint64_t seed,
                               void *stream);
 
-/* Backward of the epilogue.  g_y and g_yn (nullable) are the upstream gradients of
+/* Backward of the epilogue.  y may be NULL when the forward did not keep it (the last layer's output is read by
+ * nobody: lkg_act_layernorm_fwd_f32 accepts y == NULL when yn is given); it is then recomputed from z, the saved
+ * statistics, gamma, beta and the dropout seed for the rows that need it.  g_y and g_yn (nullable) are the upstream gradients of
  * the two outputs; writes g_z (n x d) and ACCUMULATES g_gamma / g_beta (atomic,
  * zero-initialised by the caller).  g_z_rowmax (nullable, float[n]) receives max |g_z[i,:]|:
  * the row scale of the data-gradient GEMM that consumes g_z (lkg_gemm_tall_f32), for free.
@@ -354,7 +357,7 @@ int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz,
  * is over the <= 3B rows the loss reaches -- or over the gradient's frontier, when g_y is row-sparse too (its rows
  * must then be in the list; g_y is read for every listed row) -- instead of N.                              */
 int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
-                              const float *gamma, const float *y, int64_t ldy,
+                              const float *gamma, const float *beta, const float *y, int64_t ldy,
                               const float *save_mean, const float *save_rstd, const float *g_y,
                               int64_t ldgy, const float *g_yn, int64_t ldgyn, float norm_eps,
                               float *g_z, int64_t ldgz, float *g_gamma, float *g_beta,

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const fl
         a.v[k] = o;
         nn += a.live(k, d, lane) ? o * o : 0.f;
     }
-    a.store(y + row * ldy, d, lane);
+    if (y) a.store(y + row * ldy, d, lane);       // (nobody reads the LAST layer's y: only its normalised copy is kept)
     if (lane == 0) {
         save_mean[row] = mean;
         save_rstd[row] = rstd;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const fl
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
                                                           float slope, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
                                                           const float *__restrict__ y, long ldy,
                                                           const float *__restrict__ save_mean,
                                                           const float *__restrict__ save_rstd,
@@ -171,7 +172,25 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
             G.load(z, 0, lane);   // zeros
         if (has_gyn) {
             RowRegs<W, CPL> gn;
-            yy.load(y + row * ldy, d, lane);
+            if (y) {
+                yy.load(y + row * ldy, d, lane);
+            } else {          // y was not kept (the last layer): the same arithmetic as the forward, for this row
+                RowRegs<W, CPL> bb;
+                bb.load(beta, d, lane);
+                const float mean_ = save_mean[row], rstd_ = save_rstd[row];
+                const float inv_keep_ = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+                const unsigned rkey_ = drop_row_key(seed, (unsigned long long)row);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float t_ = zz.v[k];
+                    float o = ((t_ > 0.f ? t_ : t_ * slope) - mean_) * rstd_ * gam.v[k] + bb.v[k];
+                    if (drop_p > 0.f) {
+                        const int e = (lane + 64 * (k / W)) * W + (k % W);
+                        o *= drop_scale(rkey_, (unsigned)e, drop_p, inv_keep_);
+                    }
+                    yy.v[k] = zz.live(k, d, lane) ? o : 0.f;
+                }
+            }
             gn.load(g_yn + row * ldgyn, d, lane);
             float n2 = 0.f, dt = 0.f;
 #pragma unroll
@@ -525,12 +544,12 @@ extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, i
                                          float *yn, int64_t ldyn, float norm_eps, float *save_mean, float *save_rstd,
                                          float drop_p, uint64_t seed, void *stream) {
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_fwd_f32: dropout probability %g outside [0,1)", drop_p);
-    LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldy >= d && (!yn || ldyn >= d), "lkg_act_layernorm_fwd_f32: bad sizes");
+    LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && (!y || ldy >= d) && (!yn || ldyn >= d), "lkg_act_layernorm_fwd_f32: bad sizes");
     if (n == 0) return LKG_OK;
-    LKG_REQUIRE(z && gamma && beta && y && save_mean && save_rstd, "lkg_act_layernorm_fwd_f32: null pointer");
+    LKG_REQUIRE(z && gamma && beta && (y || yn) && save_mean && save_rstd, "lkg_act_layernorm_fwd_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = d % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && (!yn || ldyn % 4 == 0) && lkg_aligned16(z) &&
-                     lkg_aligned16(y) && lkg_aligned16(gamma) && lkg_aligned16(beta) && (!yn || lkg_aligned16(yn));
+    const bool vec = d % 4 == 0 && ldz % 4 == 0 && (!y || ldy % 4 == 0) && (!yn || ldyn % 4 == 0) && lkg_aligned16(z) &&
+                     (!y || lkg_aligned16(y)) && lkg_aligned16(gamma) && lkg_aligned16(beta) && (!yn || lkg_aligned16(yn));
     const dim3 grid((unsigned)((n + 3) / 4));
     LKG_ROW_DISPATCH(act_ln_fwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, beta, eps, y, (long)ldy, yn,
                      (long)ldyn, norm_eps, save_mean, save_rstd, drop_p, (unsigned long long)seed);
@@ -539,7 +558,8 @@ extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, i
 }
 
 extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, int64_t ldz, float slope,
-                                         const float *gamma, const float *y, int64_t ldy, const float *save_mean,
+                                         const float *gamma, const float *beta, const float *y, int64_t ldy,
+                                         const float *save_mean,
                                          const float *save_rstd, const float *g_y, int64_t ldgy, const float *g_yn,
                                          int64_t ldgyn, float norm_eps, float *g_z, int64_t ldgz, float *g_gamma,
                                          float *g_beta, float drop_p, uint64_t seed, float *g_z_rowmax,
@@ -552,17 +572,17 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
     if (n == 0) return LKG_OK;
-    LKG_REQUIRE(z && gamma && save_mean && save_rstd && g_z && g_gamma && g_beta && (!g_yn || y),
-                "lkg_act_layernorm_bwd_f32: null pointer");
+    LKG_REQUIRE(z && gamma && save_mean && save_rstd && g_z && g_gamma && g_beta && (!g_yn || y || beta),
+                "lkg_act_layernorm_bwd_f32: null pointer (g_yn needs y, or beta to recompute it)");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = d % 4 == 0 && ldz % 4 == 0 && ldgz % 4 == 0 && (!g_y || ldgy % 4 == 0) &&
-                     (!g_yn || (ldgyn % 4 == 0 && ldy % 4 == 0)) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
+                     (!g_yn || (ldgyn % 4 == 0 && (!y || ldy % 4 == 0))) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
                      lkg_aligned16(gamma) && (!g_y || lkg_aligned16(g_y)) &&
-                     (!g_yn || (lkg_aligned16(g_yn) && lkg_aligned16(y)));
+                     (!g_yn || (lkg_aligned16(g_yn) && (!y || lkg_aligned16(y)) && (y || lkg_aligned16(beta))));
     const int64_t n_work = row_ids ? n_row_ids : n;
     if (n_work == 0) return LKG_OK;
     const dim3 grid((unsigned)std::min<int64_t>((n_work + 3) / 4, 1024));
-    LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, y, (long)ldy, save_mean,
+    LKG_ROW_DISPATCH(act_ln_bwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, beta, y, (long)ldy, save_mean,
                      save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, g_beta, drop_p,
                      (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr, sparse_out,
                      (const long *)row_ids, (long)n_row_ids);

@@ -103,6 +103,7 @@ class Aggregator(nn.Module):
                 self.mlp_layer_norms = nn.ModuleList(nn.LayerNorm(hid) for _ in range(self.num_layers - 1))
         self.last_normalized = None
         self.norm_out = None   # set by the encoder: the concat-buffer slice the normalised copy goes to
+        self.want_output = True   # ... and False for the last layer: nobody reads its un-normalised output
 
     # (1-a) hi + a W0 h0, then @ ((1-b) + b W)   -- (1-b) lands on every entry of W (model.py:96)
     def residual_connection(self, hi, h0, lamda, alpha, l):
@@ -128,7 +129,8 @@ class Aggregator(nn.Module):
             for e in extra_sum:
                 z = ops.axpby(z, e)
             slope = 1.0   # the second LayerNorm has no activation in front: slope 1 = identity
-        y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p, yn_out=self.norm_out)
+        y, yn = ops.act_layernorm(z, ln.weight, ln.bias, want_norm=True, slope=slope, drop_p=p, yn_out=self.norm_out,
+                                  want_y=self.want_output)
         self.last_normalized = yn
         return y
 
@@ -300,6 +302,7 @@ class LiteralKG(nn.Module):
         kept = [cur]
         for idx, layer in enumerate(self.aggregator_layers):
             layer.norm_out = cb.slot(idx + 1)
+            layer.want_output = idx + 1 < len(self.aggregator_layers)     # (the last layer's y is read by nobody)
             # layer 1 on the device structure: its SpMM also leaves the layer input in slot 0 (no copy pass) and its
             # backward sums the two gradients of that input in the same launch
             a_k = _KeepingAttention(att, cb.slot(0)) if (idx == 0 and isinstance(att, AttentionCSR)) else att
@@ -307,6 +310,7 @@ class LiteralKG(nn.Module):
                 cur = layer(cur, a_k, kept, self.lamda, self.alpha, idx + 1)
             finally:
                 layer.norm_out = None
+                layer.want_output = True
             if a_k is not att and a_k.kept is not None:
                 kept[0] = a_k.kept
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused

@@ -819,20 +819,24 @@ class _ActLayerNorm(Function):
     The dropout mask is counter-based (seed, element index) and regenerated in the backward."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed, yn_out):
+    def forward(ctx, z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed, yn_out, want_y):
         _need_gpu(z, gamma, beta)
         z = _f32_rows(z)
         n, d = z.shape
-        y = torch.empty((n, d), dtype=torch.float32, device=z.device)
+        if not want_y and not want_norm:
+            raise ValueError("act_layernorm: neither output wanted")
+        # (the LAST layer's y is read by nobody -- only its normalised copy is kept: 4 n d bytes not written; the
+        # backward recomputes the few rows of y it needs)
+        y = torch.empty((n, d), dtype=torch.float32, device=z.device) if want_y else None
         yn = None
         if want_norm:   # yn_out: a column slice of the concat buffer (CatBuffer), written in place
             yn = yn_out if yn_out is not None else torch.empty((n, d), dtype=torch.float32, device=z.device)
         mean = torch.empty(n, dtype=torch.float32, device=z.device)
         rstd = torch.empty(n, dtype=torch.float32, device=z.device)
         N.call("lkg_act_layernorm_fwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta),
-               float(eps), N.ptr(y), _ld(y), N.ptr(yn), _ld(yn) if yn is not None else 0, float(norm_eps),
-               N.ptr(mean), N.ptr(rstd), float(drop_p), int(seed), _stream())
-        ctx.save_for_backward(z, gamma, y, mean, rstd)
+               float(eps), N.ptr(y), _ld(y) if y is not None else 0, N.ptr(yn), _ld(yn) if yn is not None else 0,
+               float(norm_eps), N.ptr(mean), N.ptr(rstd), float(drop_p), int(seed), _stream())
+        ctx.save_for_backward(z, gamma, beta, mean, rstd, *([y] if y is not None else []))
         ctx.cfg = (slope, norm_eps, drop_p, seed)
         ctx.set_materialize_grads(False)
         if want_norm:
@@ -841,10 +845,11 @@ class _ActLayerNorm(Function):
 
     @staticmethod
     def backward(ctx, gy, gyn):
-        z, gamma, y, mean, rstd = ctx.saved_tensors
+        z, gamma, beta, mean, rstd, *kept_y = ctx.saved_tensors
+        y = kept_y[0] if kept_y else None
         slope, norm_eps, drop_p, seed = ctx.cfg
         n, d = z.shape
-        none = (None,) * 10
+        none = (None,) * 11
         if gy is None and gyn is None:
             return none
         rows_n = tagged_rows(gyn)        # a loss's row-sparse gradient: the kernel skips the zero rows
@@ -866,8 +871,8 @@ class _ActLayerNorm(Function):
         else:
             gz = torch.empty((n, d), dtype=torch.float32, device=z.device)
             rm = torch.empty(n, dtype=torch.float32, device=z.device) if _wants_rowmax(n) else None   # for the Linear's data gradient
-        N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(y), _ld(y),
-               N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
+        N.call("lkg_act_layernorm_bwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta), N.ptr(y),
+               _ld(y) if y is not None else 0, N.ptr(mean), N.ptr(rstd), N.ptr(gy), _ld(gy) if gy is not None else 0, N.ptr(gyn),
                _ld(gyn) if gyn is not None else 0, float(norm_eps), N.ptr(gz), _ld(gz), N.ptr(gg), N.ptr(gb),
                float(drop_p), int(seed), N.ptr(rm), N.ptr(_flags(rows_n)), int(sparse_out),
                N.ptr(ids) if sparse_out else None, ids.numel() if sparse_out else 0, _stream())
@@ -880,10 +885,13 @@ def new_seed() -> int:
 
 
 def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS,
-                  drop_p: float = 0.0, seed: Optional[int] = None, yn_out: Optional[torch.Tensor] = None):
+                  drop_p: float = 0.0, seed: Optional[int] = None, yn_out: Optional[torch.Tensor] = None,
+                  want_y: bool = True):
+    """(y, yn); want_y = False: y is not produced (returned as None) -- the last layer, whose output only its normalised
+    copy survives."""
     if drop_p > 0 and seed is None:
         seed = new_seed()
-    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0, yn_out)
+    return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0, yn_out, want_y)
 
 
 # ----------------------------------------------------------------------------- concat without the copy
