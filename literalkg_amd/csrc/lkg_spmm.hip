@@ -408,6 +408,90 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
     }
 }
 
+// Row-sparse x, FOUR rows per wave.  With almost nothing to gather a row is a chain of dependent round trips (rowptr ->
+// col -> flag) and nothing else; one wave per row leaves the launch bound by wave turnover (1 M rows: 0.43 ms).  Here
+// the four 16-lane quarters of a wave scan four consecutive rows at once -- 16 entries each per pass, one ballot for
+// all four -- and the (rare) flagged entries are gathered by the whole wave, one at a time, into the accumulators of
+// their row; then the wave writes the four rows (64 lanes x 16 bytes x CPL).  Rows over long_thresh entries are left
+// to the team workgroups of spmm_csr_kernel (a second, tiny launch).
+template <int CPL, bool FULL>
+__global__ __launch_bounds__(256) void spmm_flagged4_kernel(int n_rows, int nchunk, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col, const float *__restrict__ val,
+                                                             const float *__restrict__ x, long ldx,
+                                                             float *__restrict__ out, long ldo,
+                                                             const float *__restrict__ self, long ld_self, int n_long,
+                                                             int long_thresh, SpmmExtra ex) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, ql = lane & 15;
+    const int task = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row_q = task * 4 + q;                         // this quarter's row
+    int start = 0, len = 0;
+    if (row_q < n_rows) {
+        start = rowptr[row_q];
+        len = rowptr[row_q + 1] - start;
+        if (n_long > 0 && len > long_thresh) len = 0;       // (a team workgroup's row)
+    }
+    int maxlen = len;
+    maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
+    maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
+    float4 acc[4][CPL];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[r][i] = f4_zero();
+    unsigned any = 0;                                       // bit r: row r of the four met a flagged entry
+    for (int p = 0; p < maxlen; p += 16) {
+        const int j = p + ql;
+        const bool in = j < len;
+        const int jj = start + (in ? j : 0);
+        const int c = len > 0 ? col[jj] : 0;
+        unsigned long long m = __ballot(in && ex.x_rows[c] != 0);
+        if (m == 0) continue;                               // (wave-uniform)
+        const float v = in ? val[jj] : 0.f;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int r = b >> 4;                           // (wave-uniform)
+            const int cc = __builtin_amdgcn_readlane(c, b);
+            const float vv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), b));
+            const float4 *src = reinterpret_cast<const float4 *>(x + (long)cc * ldx);
+            any |= 1u << r;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int chunk = lane + i * 64;
+                const float4 xv = (FULL || chunk < nchunk) ? src[chunk] : f4_zero();
+                if (r == 0) f4_fma(acc[0][i], vv, xv);
+                else if (r == 1) f4_fma(acc[1][i], vv, xv);
+                else if (r == 2) f4_fma(acc[2][i], vv, xv);
+                else f4_fma(acc[3][i], vv, xv);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = task * 4 + r;
+        if (row >= n_rows) break;
+        const int rfull = rowptr[row + 1] - rowptr[row];    // (team rows: written by their workgroup, not here)
+        if (n_long > 0 && rfull > long_thresh) continue;
+        const float *own = self && (!ex.self_rows || ex.self_rows[row]) ? self + (long)row * ld_self : nullptr;
+        const float *own2 = ex.add2_row(row);
+        if (ex.out_rows) {
+            if (!(((any >> r) & 1) || own || own2)) continue;
+            if (lane == 0) ex.out_rows[row] = 1;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(out + (long)row * ldo);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int chunk = lane + i * 64;
+            if (FULL || chunk < nchunk) {
+                float4 a = acc[r][i];
+                if (own) f4_fma(a, 1.f, reinterpret_cast<const float4 *>(own)[chunk]);
+                if (own2) f4_fma(a, 1.f, reinterpret_cast<const float4 *>(own2)[chunk]);
+                dst[chunk] = a;
+            }
+        }
+    }
+}
+
 template <typename V, int LPE, int U, bool FULL>
 int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
                    int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows,
@@ -514,6 +598,38 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     // flight and a 128-column slab of the source table is 2-4x more likely to be served from the 256 MiB
     // Infinity Cache -- at the price of re-reading the (col, val) stream once per slab (+8 B per entry per slab).
     // The scalar (unaligned) path keeps up to 256 columns per launch.
+    if (x_rows && vec && !copy_dst && !rowmax_out && d <= 1024) {
+        // row-sparse x: four rows per wave (spmm_flagged4_kernel); the rows over long_thresh entries on team workgroups
+        const int nchunk = d / 4, cpl = (nchunk + 63) / 64;
+        const bool full = nchunk == 64 * cpl;
+        const int64_t tasks = (n_rows + 3) / 4, blocks = (tasks + 3) / 4;
+        LKG_REQUIRE(blocks * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)", (long long)blocks);
+#define LKG_F4(CPL_)                                                                                                   \
+    case CPL_:                                                                                                         \
+        if (full)                                                                                                      \
+            hipLaunchKernelGGL((spmm_flagged4_kernel<CPL_, true>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows, \
+                               nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self, n_long,     \
+                               long_thresh, ex);                                                                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((spmm_flagged4_kernel<CPL_, false>), dim3((unsigned)blocks), dim3(256), 0, s, (int)n_rows, \
+                               nchunk, rowptr, col, val, x, (long)ldx, out, (long)ldo, self, (long)ld_self, n_long,     \
+                               long_thresh, ex);                                                                       \
+        break;
+        switch (cpl) { LKG_F4(1) LKG_F4(2) LKG_F4(3) LKG_F4(4) }
+#undef LKG_F4
+        LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
+        if (n_long == 0) return LKG_OK;
+        // the long rows: the team workgroups of the general kernel alone (n_rows = 0 leaves no ordinary row to it)
+        for (int c0 = 0; c0 < d; c0 += 256) {
+            const int dc = min(256, d - c0);
+            const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr, nullptr, 0, nullptr, 0, nullptr,
+                                x_rows, self ? self_rows : nullptr, out_rows};
+            const int rc = dispatch<float4>(0, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, self ? self + c0 : nullptr,
+                                            ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s);
+            if (rc != LKG_OK) return rc;
+        }
+        return LKG_OK;
+    }
     // (over a row-sparse x almost nothing is gathered: one pass over the entry stream per 256 columns, not per 128)
     const int block_cols = (vec && !x_rows) ? 128 : 256;
     if (d > block_cols && d % block_cols == 0)     // equal slabs: one launch, slab-major workgroup order
