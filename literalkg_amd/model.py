@@ -294,18 +294,25 @@ class LiteralKG(nn.Module):
     def gate_embeddings(self):
         return self._gate(self.entity_embed.weight, *self._literals())
 
-    def gat_embeddings(self):
+    def gat_embeddings(self, defer_slot0: bool = False):
+        """The concatenated table (model.py:298-314).  defer_slot0 (no gate, no linear_gat): the copy of the raw entity
+        table into column slot 0 is NOT made -- returns (table with slot 0 pending, raw table); a reader of <= 3B rows
+        (the TransR loss) takes those columns from the raw table, anybody else goes through the ``gat_embed`` property,
+        which completes the table first."""
         att = self._attention()
         # every producer writes its column slice of the concatenated table directly (no torch.cat pass)
         cb = ops.CatBuffer(self.n_entities, self.conv_dim_list, self.entity_embed.weight.device)
         cur = self._gate(self.entity_embed.weight, *self._literals(), out=cb.slot(0))
+        defer = (defer_slot0 and cur is self.entity_embed.weight and self.scale_gat_dim is None
+                 and isinstance(att, AttentionCSR))
         kept = [cur]
         for idx, layer in enumerate(self.aggregator_layers):
             layer.norm_out = cb.slot(idx + 1)
             layer.want_output = idx + 1 < len(self.aggregator_layers)     # (the last layer's y is read by nobody)
             # layer 1 on the device structure: its SpMM also leaves the layer input in slot 0 (no copy pass) and its
             # backward sums the two gradients of that input in the same launch
-            a_k = _KeepingAttention(att, cb.slot(0)) if (idx == 0 and isinstance(att, AttentionCSR)) else att
+            a_k = (_KeepingAttention(att, None if defer else cb.slot(0))
+                   if (idx == 0 and isinstance(att, AttentionCSR)) else att)
             try:
                 cur = layer(cur, a_k, kept, self.lamda, self.alpha, idx + 1)
             finally:
@@ -314,6 +321,11 @@ class LiteralKG(nn.Module):
             if a_k is not att and a_k.kept is not None:
                 kept[0] = a_k.kept
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused
+        if defer_slot0:
+            cat = ops.assemble_cat(cb, kept, pending=(0,) if defer else ())
+            if self.scale_gat_dim is not None:
+                cat = ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
+            return cat, (self.entity_embed.weight if defer else None)
         cat = ops.assemble_cat(cb, kept)
         if self.scale_gat_dim is not None:
             return ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
@@ -372,8 +384,16 @@ class LiteralKG(nn.Module):
             k = int(self.pre_training_neg_rate)
             if k >= self.group_reuse_min_rate and ops.is_grouped_batch(h, r, pos_t, k):
                 group = k
-        self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         keep = self.last_scores if not self.training else None
+        if self.scoring == "transr" and not self._can_prune():
+            # the loss reads <= 3B rows: the N-row copy of the raw entity table into slot 0 of the concatenated table is
+            # deferred (made only if somebody asks for self.gat_embed), its columns are read from the raw table
+            self.gat_rows = None
+            table, raw = self.gat_embeddings(defer_slot0=True)
+            self._gat_state = (table, raw)        # (a tuple: nn.Module would register a bare Parameter attribute)
+            return ops.transr_loss(table, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
+                                   self.kg_l2loss_lambda, keep, group, self._table_grad_stays_inside(), slot0=raw)
+        self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         sparse = self._table_grad_stays_inside()
         if self.scoring == "transr":
             return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
@@ -381,12 +401,26 @@ class LiteralKG(nn.Module):
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
                                self.kg_l2loss_lambda, keep, sparse)
 
+    @property
+    def gat_embed(self):
+        """The table of the last encoder pass (the reference keeps it as an attribute, model.py:366).  A slot-0 copy that
+        the loss deferred is made here, on first access."""
+        table, raw = self.__dict__.get("_gat_state", (None, None))
+        if table is not None and raw is not None:
+            ops.fill_slot(table, 0, raw)
+            self._gat_state = (table, None)
+        return table
+
+    @gat_embed.setter
+    def gat_embed(self, table):
+        self._gat_state = (table, None)
+
     def _table_grad_stays_inside(self) -> bool:
         """Is ``self.gat_embed`` the full N-row table of gat_embeddings()?  Its gradient (<= 3B non-zero rows) is then
         consumed during the backward pass by this package's Functions only -- column slices of the concatenated table
         (>= 2 slots, so no slice can become a parameter's .grad as it is) or linear_gat's backward -- and the loss may
         hand back the shared all-zero table of ops._RowScratch instead of filling N x C zeros per step."""
-        return self.gat_rows is None and len(self.conv_dim_list) >= 2
+        return self.gat_rows is None and len(self.conv_dim_list) >= 2     # (gat_rows: set by the pruned path)
 
     # ------------------------------------------------------------------ a4/a5 attention refresh
     def _structure_for(self, h_list, t_list, r_list, relations) -> KGStructure:

@@ -912,9 +912,11 @@ class CatBuffer:
 
 class _AssembleCat(Function):
     @staticmethod
-    def forward(ctx, holder: CatBuffer, *parts):
+    def forward(ctx, holder: CatBuffer, pending, *parts):
         for k, p in enumerate(parts):
             s = holder.slot(k)
+            if k in pending:                     # left unwritten on purpose: the caller completes it on demand (fill_slot)
+                continue
             if p.data_ptr() != s.data_ptr() or p.stride() != s.stride():
                 s.copy_(p)                       # a part that was not produced in place (e.g. the raw entity table)
         ctx.offsets = holder.offsets
@@ -924,11 +926,20 @@ class _AssembleCat(Function):
     def backward(ctx, g):
         o = ctx.offsets
         rows = tagged_rows(g)            # the column slices of a row-sparse gradient are row-sparse
-        return (None, *[tag_rows(g[:, o[k]:o[k + 1]], rows) for k in range(len(o) - 1)])
+        return (None, None, *[tag_rows(g[:, o[k]:o[k + 1]], rows) for k in range(len(o) - 1)])
 
 
-def assemble_cat(holder: CatBuffer, parts: Sequence[torch.Tensor]) -> torch.Tensor:
-    return _AssembleCat.apply(holder, *parts)
+def assemble_cat(holder: CatBuffer, parts: Sequence[torch.Tensor], pending: Sequence[int] = ()) -> torch.Tensor:
+    """The concatenated table; ``pending`` slots are NOT written (their columns hold garbage until fill_slot)."""
+    return _AssembleCat.apply(holder, tuple(pending), *parts)
+
+
+def fill_slot(table: torch.Tensor, col0: int, src: torch.Tensor):
+    """table[:, col0 : col0 + src.shape[1]] = src by a kernel of this library (no autograd version bump: the table may
+    already be saved for a backward that does not read these columns)."""
+    src = _f32_rows(src.detach())
+    n, w = src.shape
+    N.call("lkg_gather_rows_f32", n, w, N.ptr(src), _ld(src), None, None, table.data_ptr() + 4 * col0, _ld(table), _stream())
 
 
 # ----------------------------------------------------------------------------- K6 gate blend
@@ -1155,7 +1166,7 @@ class _TransRLoss(Function):
     projected ONCE per group: 2 (2 + K) / K B C D flops instead of 6 B C D."""
 
     @staticmethod
-    def forward(ctx, emb, relemb, trans_m, h, r, pt, nt, lam, keep, group, sparse_rows):
+    def forward(ctx, emb, relemb, trans_m, h, r, pt, nt, lam, keep, group, sparse_rows, slot0):
         _need_gpu(emb, relemb, trans_m, h, r, pt, nt)
         ctx.sparse_rows = bool(sparse_rows)
         emb, relemb = _f32_rows(emb), _f32_rows(relemb)
@@ -1193,9 +1204,18 @@ class _TransRLoss(Function):
         x = torch.empty((2 * n_g + b, c), dtype=torch.float32, device=dev)
         p = torch.empty((2 * n_g + b, dout), dtype=torch.float32, device=dev)
         parts = ((hg, perm, seg, 0, n_g), (pg, perm, seg, n_g, n_g), (nt, perm_n, seg_n, 2 * n_g, b))
+        # slot0: the first columns of emb are not filled in (assemble_cat's pending slot): they are read from the table
+        # they would be a copy of (the raw entity table) -- the copy of N rows is never made for the <= 3B rows read here
+        w0 = 0
+        if slot0 is not None:
+            slot0 = _f32_rows(slot0)
+            w0 = slot0.shape[1]
         for ids, pm, sg, off, rows in parts:
-            N.call("lkg_gather_rows_f32", rows, c, N.ptr(emb), _ld(emb), N.ptr(ids), N.ptr(pm), N.ptr(x[off:]), c,
-                   _stream())
+            if w0:
+                N.call("lkg_gather_rows_f32", rows, w0, N.ptr(slot0), _ld(slot0), N.ptr(ids), N.ptr(pm), N.ptr(x[off:]), c,
+                       _stream())
+            N.call("lkg_gather_rows_f32", rows, c - w0, emb.data_ptr() + 4 * w0, _ld(emb), N.ptr(ids), N.ptr(pm),
+                   x[off:].data_ptr() + 4 * w0, c, _stream())
         # the three row blocks are each sorted by relation: 3 R row ranges over the R matrices, ONE grouped launch
         seg_all = torch.cat([seg, seg[1:] + n_g, seg_n[1:] + 2 * n_g])
         _grouped(1, seg_all, max(b, n_g), x, trans_m, p, 0, dout, c, False, False, 0.0, stride_b=c * dout, b_period=n_rel)
@@ -1237,11 +1257,14 @@ class _TransRLoss(Function):
             _grouped(2, sg, rows, xi, gi, g_w, c, dout, 0, True, False, 0.0 if i == 0 else 1.0, stride_c=c * dout)
             N.call("lkg_scatter_add_rows_f32", rows, c, N.ptr(gx[off:]), c, N.ptr(ids), N.ptr(pm), N.ptr(g_emb),
                    _ld(g_emb), _stream())
-        return g_emb, g_rel, g_w, None, None, None, None, None, None, None, None
+        return g_emb, g_rel, g_w, None, None, None, None, None, None, None, None, None
 
 
-def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group: int = 1, sparse_rows: bool = False):
-    return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep, group, sparse_rows)
+def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group: int = 1, sparse_rows: bool = False,
+                slot0: Optional[torch.Tensor] = None):
+    """slot0: emb's first slot0.shape[1] columns are pending (assemble_cat) and are read from this table instead."""
+    return _TransRLoss.apply(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep, group, sparse_rows,
+                             slot0.detach() if slot0 is not None else None)
 
 
 # ----------------------------------------------------------------------------- f1 fine-tuning head

@@ -1630,3 +1630,39 @@ def test_gate_backward_statistics_ride_along(ops, gpu_device, d, n_w):
         want = (gpz64.t() @ w[:, :n_w].double())                       # [2d x n_w]
         got = st[5 * d:].view(n_w, 2 * d).t().double()
         assert float((got - want).abs().max()) <= 2e-6 * float((gpz64.abs().t() @ w[:, :n_w].double()).max())
+
+
+def test_deferred_slot0_copy_is_made_on_demand(L, ops, O, gpu_device):
+    """pre_training with TransR and no gate: the copy of the raw entity table into slot 0 of the concatenated table is not
+    made by the step; `model.gat_embed` completes the table on first access -- also between forward and backward -- and
+    the module's parameter / state_dict surface is untouched."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, dim = 30_000, 64
+    h, t, r = make_kg(n, 120_000, seed=3)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=1, aggregation_type="gcn",
+                        kg_l2loss_lambda=1e-4, device=gpu_device)
+    torch.manual_seed(2)
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), None, None, scoring="transr").to(gpu_device).eval()
+    keys = set(m.state_dict().keys())
+    n_params = len(list(m.parameters()))
+    batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 50, 3, seed=4)]
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    table, raw = m._gat_state
+    assert raw is not None                                      # pending: the step did not copy
+    ops.fill_slot(table, 0, torch.full((n, dim), float("nan"), device=gpu_device))   # whatever was there must not matter
+    got = m.gat_embed                                           # ... completes the table
+    assert m._gat_state[1] is None and torch.equal(got[:, :dim].detach(), m.entity_embed.weight.detach())
+    loss.backward()                                             # (no version-counter complaint: the fill is a library kernel)
+    g_sparse = {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+    assert set(m.state_dict().keys()) == keys and len(list(m.parameters())) == n_params
+    # the same step with the copy made by the SpMM epilogue (the other losses' path)
+    m.zero_grad(set_to_none=True)
+    full = m.gat_embeddings()
+    loss2 = ops.transr_loss(full, m.relation_embed.weight, m.gat_trans_M, *batch, m.kg_l2loss_lambda)
+    loss2.backward()
+    assert abs(float(loss) - float(loss2)) <= 1e-6 * abs(float(loss2))
+    assert torch.equal(full.detach(), got.detach())
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            assert float((v.grad - g_sparse[k]).abs().max()) <= 5e-5 * (float(v.grad.abs().max()) + 1e-30), k
