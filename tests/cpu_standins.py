@@ -67,7 +67,7 @@ def patch_ops():
     from literalkg_amd import ops
 
     def act_layernorm(z, gamma, beta, want_norm=True, slope=ops.LEAKY_SLOPE, eps=ops.LN_EPS, norm_eps=ops.NORMALIZE_EPS,
-                      drop_p=0.0, seed=None, yn_out=None):
+                      drop_p=0.0, seed=None, yn_out=None, want_y=True):
         assert drop_p == 0.0, "the rehearsal runs without dropout"
         a = z if slope == 1.0 else F.leaky_relu(z, slope)
         y = F.layer_norm(a, (z.shape[1],), gamma, beta, eps)
