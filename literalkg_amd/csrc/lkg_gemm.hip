@@ -630,6 +630,10 @@ extern "C" int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t
     if (beta == 0.f && tiles < 256 && k >= 8192) {
         splits = (int)std::min<long>(std::min<long>(1024 / tiles, k / 2048), 65535);
         if (splits < 2) splits = 1;
+    } else if (beta == 0.f && tiles <= 32 && k >= 2048) {
+        // a few thousand rows (the weight gradient over the rows a loss reaches): a handful of tiles would walk k alone
+        splits = (int)std::min<long>(256 / tiles, k / 256);
+        if (splits < 2) splits = 1;
     }
     g.k_splits = splits;
     if (splits > 1) {
