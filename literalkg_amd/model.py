@@ -379,11 +379,9 @@ class LiteralKG(nn.Module):
     def calc_triplet_loss(self, h, r, pos_t, neg_t):
         # generate_kg_batch repeats every sampled (h, r, t+) pre_training_neg_rate times (dataloader.py:318-330): such
         # a batch projects h and t+ once per group.  Checked on the ids (any other batch takes the general path).
-        group = 1
-        if self.scoring == "transr" and self.group_reuse:
-            k = int(self.pre_training_neg_rate)
-            if k >= self.group_reuse_min_rate and ops.is_grouped_batch(h, r, pos_t, k):
-                group = k
+        check, k = None, int(self.pre_training_neg_rate)
+        if self.scoring == "transr" and self.group_reuse and k >= self.group_reuse_min_rate:
+            check = ops.GroupedCheck(h, r, pos_t, k)      # queued now, answered just before the loss (no idle device)
         keep = self.last_scores if not self.training else None
         if self.scoring == "transr" and not self._can_prune():
             # the loss reads <= 3B rows: the N-row copy of the raw entity table into slot 0 of the concatenated table is
@@ -391,11 +389,13 @@ class LiteralKG(nn.Module):
             self.gat_rows = None
             table, raw = self.gat_embeddings(defer_slot0=True)
             self._gat_state = (table, raw)        # (a tuple: nn.Module would register a bare Parameter attribute)
+            group = k if (check is not None and check.result()) else 1
             return ops.transr_loss(table, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
                                    self.kg_l2loss_lambda, keep, group, self._table_grad_stays_inside(), slot0=raw)
         self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
         sparse = self._table_grad_stays_inside()
         if self.scoring == "transr":
+            group = k if (check is not None and check.result()) else 1
             return ops.transr_loss(self.gat_embed, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
                                    self.kg_l2loss_lambda, keep, group, sparse)
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,

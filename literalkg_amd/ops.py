@@ -1144,19 +1144,38 @@ def _grouped(mode, seg, max_len, a, b, out, m, n, k, trans_a, trans_b, beta, str
            out.stride(-2), stride_c, _stream())
 
 
+class GroupedCheck:
+    """Is the batch whole groups of ``group_size`` consecutive rows with identical (h, r, t+) -- the layout of
+    DataLoader.generate_kg_batch (dataloader.py:318-330)?  The answer decides tensor shapes, so the host has to wait for
+    it -- but not where it asks: the check kernel and the copy of its verdict to pinned memory are queued when the object
+    is made (BEFORE the encoder), ``result()`` waits for that event only (just before the loss: the encoder's launches
+    are queued by then and the device never idles behind the wait)."""
+
+    def __init__(self, h, r, pos_t, group_size: int):
+        self.answer = None
+        b = h.numel()
+        if group_size <= 1 or b == 0 or b % group_size:
+            self.answer = False
+            return
+        _need_gpu(h, r, pos_t)
+        h, r, pos_t = _i64(h), _i64(r), _i64(pos_t)
+        bad = torch.empty(1, dtype=torch.int32, device=h.device)
+        N.call("lkg_check_grouped_i64", b, int(group_size), N.ptr(h), N.ptr(r), N.ptr(pos_t), N.ptr(bad), _stream())
+        self.host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(bad, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def result(self) -> bool:
+        if self.answer is None:
+            self.event.synchronize()
+            self.answer = int(self.host[0]) == 0
+        return self.answer
+
+
 def is_grouped_batch(h, r, pos_t, group_size: int) -> bool:
-    """True when the batch consists of whole groups of ``group_size`` consecutive rows with identical (h, r, t+) --
-    the layout of DataLoader.generate_kg_batch (dataloader.py:318-330).  One tiny kernel and one host sync; the
-    module asks BEFORE it queues the encoder, where a driver shaped like main_pretraining.py has just synchronised
-    anyway (its blocking id upload, main_pretraining.py:104-107)."""
-    b = h.numel()
-    if group_size <= 1 or b == 0 or b % group_size:
-        return False
-    _need_gpu(h, r, pos_t)
-    h, r, pos_t = _i64(h), _i64(r), _i64(pos_t)
-    bad = torch.empty(1, dtype=torch.int32, device=h.device)
-    N.call("lkg_check_grouped_i64", b, int(group_size), N.ptr(h), N.ptr(r), N.ptr(pos_t), N.ptr(bad), _stream())
-    return int(bad.item()) == 0
+    """GroupedCheck, asked and answered on the spot (one host sync)."""
+    return GroupedCheck(h, r, pos_t, group_size).result()
 
 
 class _TransRLoss(Function):
