@@ -1391,6 +1391,72 @@ def test_loss_row_scratch_equals_a_fresh_zero_table(L, ops, O, gpu_device, scori
         ops._RowScratch._tables.clear()
 
 
+@pytest.mark.parametrize("layers", [1, 2])
+def test_row_sparse_backward_under_unusual_autograd_sequences(L, ops, O, gpu_device, layers):
+    """The kept-zero gradient tables and row sets (ops._RowScratch / RowSet / the gradient frontier) under call sequences a
+    plain training loop does not produce -- two forwards before ONE backward of the summed loss, gradient accumulation over
+    two backward calls, a retained graph walked twice, the table's gradient held by the caller across the next step --
+    each against the dense path (zeros_like table per step, no row sets)."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e, dim = 40_000, 300_000, 64
+    h, t, r = make_kg(n, e, seed=6)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=layers, aggregation_type="gcn",
+                        kg_l2loss_lambda=1e-4, device=gpu_device)
+    torch.manual_seed(4)
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r)).to(gpu_device).eval()
+    b1, b2 = ([torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 150, 3, seed=sd)] for sd in (21, 22))
+    ops._RowScratch._tables.clear()
+
+    def step(batch):
+        return m(*batch, device=gpu_device, mode="pre_training")
+
+    def run(seq, sparse):
+        m.zero_grad(set_to_none=True)
+        m._table_grad_stays_inside = (lambda: m.gat_rows is None) if sparse else (lambda: False)
+        seq()
+        return {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    def summed():
+        (step(b1) + step(b2)).backward()
+
+    def accumulated():
+        step(b1).backward()
+        step(b2).backward()
+
+    def retained():
+        loss = step(b1)
+        loss.backward(retain_graph=True)
+        loss.backward()
+
+    held = {}
+
+    def holding():
+        loss = step(b1)
+        table = m._gat_state[0]
+        (g_table,) = torch.autograd.grad(loss, table, retain_graph=True)
+        held["g"], held["copy"] = g_table, g_table.clone()
+        loss.backward()
+        step(b2).backward()                     # the next step must not touch the gradient the caller still holds
+
+    try:
+        for seq in (summed, accumulated, retained, holding):
+            got, want = run(seq, True), run(seq, False)
+            assert got.keys() == want.keys(), seq.__name__
+            for k in want:
+                scale = float(want[k].abs().max()) + 1e-30
+                assert float((got[k] - want[k]).abs().max()) <= 5e-5 * scale, (seq.__name__, k)
+            if seq is holding:
+                assert torch.equal(held["g"], held["copy"])
+        a, b = run(summed, True), run(accumulated, True)
+        for k in a:
+            assert float((a[k] - b[k]).abs().max()) <= 5e-5 * (float(a[k].abs().max()) + 1e-30), k
+    finally:
+        del m._table_grad_stays_inside
+        held.clear()
+        ops._RowScratch._tables.clear()
+
+
 def test_row_flag_consumers_skip_exactly_the_zero_rows(ops, gpu_device):
     """lkg_fill_rows_f32 + the row-flag forms of act_ln backward and of the SpMM's second addend against the dense forms."""
     from literalkg_amd import _native as N
