@@ -210,6 +210,9 @@ def whole_path_timings(h, t, r, n, d, dev):
                              "achieved": flops / tall_ms / 1e9, "unit": "TFLOP/s (f32-equivalent)",
                              "peak": 2500.0 / 3, "frac": flops / tall_ms / 1e9 / (2500.0 / 3),
                              "avg_launch_ms": tall_ms,
+                             # round 1 priced this product against the bf16 pipe / 6 products (416.7 TF: 0.376 then); the
+                             # same yardstick for this engine, so that the two rounds compare
+                             "frac_of_bf16_pipe_over_6": flops / tall_ms / 1e9 / (2500.0 / 6),
                              "hbm_frac": 2.0 * n * d * 4 / tall_ms / 1e6 / HBM_PEAK_GBS,
                              "note": "peak = dense fp16 MFMA peak / 3 products (the f32-input MFMA it replaces peaks at 157.3 "
                                      "TFLOP/s); this shape moves 2 GB (read x, write y): its HBM floor is ~0.31 ms, so it is as "
