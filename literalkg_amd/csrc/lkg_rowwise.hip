@@ -4,6 +4,7 @@
 // every statistic is a wave xor-shuffle reduction, every output is written once.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "lkg_common.h"
 
@@ -119,6 +120,72 @@ __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const fl
 #pragma unroll
         for (int k = 0; k < K; ++k) a.v[k] *= inv;
         a.store(yn + row * ldyn, d, lane);
+    }
+}
+
+// Narrow rows (d <= 128 floats, 16-byte path): a whole wave per row would leave half (d = 128) to seven eighths (d = 32)
+// of its lanes idle -- here LPR = 32 / 16 / 8 lanes hold a row and a wave carries 64 / LPR rows, the statistics are
+// reductions inside the LPR-lane group.  Bit-identical to act_ln_fwd_kernel<4, 1> (whose idle lanes add exact zeros
+// in the last butterfly steps).
+template <int LPR>
+__global__ __launch_bounds__(256) void act_ln_fwd_narrow_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                                 float slope, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float eps,
+                                                                 float *__restrict__ y, long ldy, float *__restrict__ yn,
+                                                                 long ldyn, float norm_eps, float *__restrict__ save_mean,
+                                                                 float *__restrict__ save_rstd, float drop_p,
+                                                                 unsigned long long seed) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sl = lane % LPR;
+    const long row_raw = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool valid = row_raw < n;                // (rows past the end are computed on a copy of the last row, never stored:
+    const long row = valid ? row_raw : n - 1;      //  the group reductions want every lane of the wave active)
+    const int e = sl * 4;
+    const bool live = e < d;
+    float a[4], g[4], b[4];
+    {   // branch-free: lanes past the row's width load its first chunk (in bounds) and drop it
+        const int ec = live ? e : 0;
+        const float4 t = *reinterpret_cast<const float4 *>(z + row * ldz + ec);
+        const float4 gg = *reinterpret_cast<const float4 *>(gamma + ec);
+        const float4 bb = *reinterpret_cast<const float4 *>(beta + ec);
+        a[0] = live ? t.x : 0.f; a[1] = live ? t.y : 0.f; a[2] = live ? t.z : 0.f; a[3] = live ? t.w : 0.f;
+        g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w;
+        b[0] = bb.x; b[1] = bb.y; b[2] = bb.z; b[3] = bb.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = a[k];
+        a[k] = t > 0.f ? t : t * slope;
+        s += live ? a[k] : 0.f;
+    }
+    const float mean = group_sum<LPR>(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float c = live ? a[k] - mean : 0.f;
+        q = fmaf(c, c, q);
+    }
+    const float rstd = 1.f / sqrtf(group_sum<LPR>(q) / (float)d + eps);
+    float nn = 0.f;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const unsigned rkey = drop_row_key(seed, (unsigned long long)row);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o = (a[k] - mean) * rstd * g[k] + b[k];
+        if (drop_p > 0.f) o *= drop_scale(rkey, (unsigned)(e + k), drop_p, inv_keep);
+        a[k] = o;
+        nn += live ? o * o : 0.f;
+    }
+    if (y && valid && live) *reinterpret_cast<float4 *>(y + row * ldy + e) = make_float4(a[0], a[1], a[2], a[3]);
+    if (sl == 0 && valid) {
+        save_mean[row] = mean;
+        save_rstd[row] = rstd;
+    }
+    if (yn) {
+        const float inv = 1.f / fmaxf(sqrtf(group_sum<LPR>(nn)), norm_eps);
+        if (valid && live)
+            *reinterpret_cast<float4 *>(yn + row * ldyn + e) = make_float4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
     }
 }
 
@@ -550,6 +617,21 @@ extern "C" int lkg_act_layernorm_fwd_f32(int64_t n, int32_t d, const float *z, i
     hipStream_t s = (hipStream_t)stream;
     const bool vec = d % 4 == 0 && ldz % 4 == 0 && (!y || ldy % 4 == 0) && (!yn || ldyn % 4 == 0) && lkg_aligned16(z) &&
                      (!y || lkg_aligned16(y)) && lkg_aligned16(gamma) && lkg_aligned16(beta) && (!yn || lkg_aligned16(yn));
+    static const bool narrow_off = getenv("LKG_ACTLN_NARROW_OFF") != nullptr;     // (A/B aid)
+    if (vec && d <= 128 && !narrow_off) {      // several rows per wave
+        const int lpr = d <= 32 ? 8 : d <= 64 ? 16 : 32;
+        const int64_t rows_per_block = 4 * (64 / lpr);
+        const dim3 grid_n((unsigned)((n + rows_per_block - 1) / rows_per_block));
+#define LKG_NARROW(LPR_)                                                                                                  \
+    hipLaunchKernelGGL((act_ln_fwd_narrow_kernel<LPR_>), grid_n, dim3(256), 0, s, (long)n, d, z, (long)ldz, slope, gamma, beta, \
+                       eps, y, (long)ldy, yn, (long)ldyn, norm_eps, save_mean, save_rstd, drop_p, (unsigned long long)seed)
+        if (lpr == 8) LKG_NARROW(8);
+        else if (lpr == 16) LKG_NARROW(16);
+        else LKG_NARROW(32);
+#undef LKG_NARROW
+        LKG_CHECK_LAUNCH("lkg_act_layernorm_fwd_f32");
+        return LKG_OK;
+    }
     const dim3 grid((unsigned)((n + 3) / 4));
     LKG_ROW_DISPATCH(act_ln_fwd_kernel, grid, (long)n, d, z, (long)ldz, slope, gamma, beta, eps, y, (long)ldy, yn,
                      (long)ldyn, norm_eps, save_mean, save_rstd, drop_p, (unsigned long long)seed);

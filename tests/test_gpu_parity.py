@@ -398,7 +398,7 @@ def test_gemm_split_k_and_slices(ops, gpu_device):
 
 
 # ----------------------------------------------------------------------------- K5 / K6 epilogues
-@pytest.mark.parametrize("d", [8, 30, 64, 256, 300, 1024])
+@pytest.mark.parametrize("d", [8, 30, 32, 64, 100, 128, 132, 256, 300, 1024])
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_act_layernorm(ops, gpu_device, d, with_norm):
     import torch.nn.functional as F

@@ -17,7 +17,8 @@ ap.add_argument("--e", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=20)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-for skew in ("zipf", "uniform"):
+ap_skews = ("zipf", "uniform") if args.e <= 20_000_000 else ("zipf",)
+for skew in ap_skews:
     h, t, r = make_kg(args.n, args.e, skew)
     g = L.KGStructure.from_triples(args.n, h, t, r, device=dev)
     d = args.dim
@@ -42,7 +43,7 @@ for skew in ("zipf", "uniform"):
                 ops.spmm_raw(g.rowptr, g.col, val, x[:, i * w:(i + 1) * w], args.n, out=out[:, i * w:(i + 1) * w],
                              long_rows=g.long_rows(False))
         return run
-    extra = [(f"fwd in {k} column slabs   ", slabs(k)) for k in (2, 4) if d % (4 * k) == 0 and d // k >= 32]
+    extra = [(f"fwd in {k} column slabs   ", slabs(k)) for k in (2, 4, 8, 16) if d % (4 * k) == 0 and d // k >= 16]
     for name, fn in extra + [
         ("fwd wave-per-row      ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out)),
         ("fwd + long-row blocks ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),

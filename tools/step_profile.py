@@ -22,6 +22,8 @@ ap.add_argument("--e", type=int, default=10_000_000)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfgs = {
+    # BASELINE config[0]'s shape (data/Small; run with --n 765957 --e 252000): the launch-bound end of the range
+    "c1": dict(embed_dim=64, relation_dim=64, conv_dim=64, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "c2": dict(embed_dim=128, relation_dim=128, conv_dim=128, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "d256": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "c3": dict(embed_dim=256, relation_dim=256, conv_dim=256, n_conv_layers=2, use_num_lit=True, use_txt_lit=True),
@@ -75,3 +77,13 @@ so = sync_time(step_opt)
 L_ = cfg.n_conv_layers
 print(f"{args.config} {args.agg} {args.scoring} prune={args.prune} fused_adam={args.fused_adam}: update_att {ua:.2f} ms ({e/ua/1e6:.2f} G edges/s) | fwd(no grad) {f_ng:.2f} | fwd {f:.2f} | fwd+bwd {s:.2f} ms "
       f"({e*L_/s/1e6:.2f} G edges/s) | +Adam {so:.2f} ms | mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+if os.environ.get("LKG_STEP_GPU_TIME"):      # device-side time of one step (event pair around it, queue kept full): host-bound if << wall
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(); step(); b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / len(ev) * 1e3
+    import numpy as np
+    print(f"fwd+bwd: wall {wall:.2f} ms per step, device span {np.median([a.elapsed_time(b) for a, b in ev]):.2f} ms")
