@@ -20,7 +20,7 @@ gb = n * d * 4 / 1e9
 z = torch.randn(n, d, device=dev); gamma = torch.randn(d, device=dev); beta = torch.randn(d, device=dev)
 cat = torch.randn(n, 2 * d, device=dev)
 for drop in (0.0, 0.1):
-    t = timeit(lambda: ops._ActLayerNorm.apply(z, gamma, beta, True, 0.01, 1e-5, 1e-12, drop, 7, None))
+    t = timeit(lambda: ops._ActLayerNorm.apply(z, gamma, beta, True, 0.01, 1e-5, 1e-12, drop, 7, None, True))
     print(f"act_ln fwd (y+yn, drop={drop})  {t:.3f} ms  {3*gb/t*1e3:.0f} GB/s")
 zg = z.clone().requires_grad_(True)
 y, yn = ops.act_layernorm(zg, gamma.requires_grad_(True), beta.requires_grad_(True), want_norm=True)
