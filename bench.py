@@ -48,7 +48,7 @@ def source_sha(path=SPMM_SOURCE):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-def pmc_traffic(by):
+def pmc_traffic(by, skew="zipf"):
     """HBM bytes per forward launch from the newest committed rocprofv3 --pmc summary (tools/pmc_traffic.py; the
     counters cannot be read from inside the process).  Reported only when that summary was taken on THIS kernel
     source (sha of lkg_spmm.hip stored in the summary) and on this workload; otherwise null."""
@@ -61,7 +61,8 @@ def pmc_traffic(by):
     if rec.get("spmm_source_sha16") != source_sha():
         return None, f"{name} was taken on another lkg_spmm.hip ({rec.get('spmm_source_sha16')} != {source_sha()})"
     tr = rec.get("traffic_bytes_fwd")
-    if tr is None or abs(tr - by) > 0.25 * by:      # different shape: not comparable
+    # (the summaries are taken on bench.py's default workload: zipf heads unless the record says otherwise)
+    if tr is None or abs(tr - by) > 0.25 * by or rec.get("skew", "zipf") != skew:      # different shape: not comparable
         return None, f"{name} was taken on another workload"
     return tr, name
 
@@ -637,7 +638,7 @@ def main():
         kind = "features" if head.startswith("features") else head
         total = res["total_entries"]
         achieved = res["fwd_bytes"] / (res["fwd_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(res["fwd_bytes"]) if world == 1 else (None, "N > 1: not collected")
+        traffic, traffic_src = pmc_traffic(res["fwd_bytes"], args.skew) if world == 1 else (None, "N > 1: not collected")
         workload = (f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
                     + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
                        "features": " + RCCL exchange (column slab <-> row block) both ways"}[kind]
