@@ -1659,6 +1659,70 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
     ops._RowScratch._tables.clear()
 
 
+@pytest.mark.parametrize("variant", ["dropout_train", "gin", "scale_gat_dim", "gatemul_3layers", "transe", "fine_tuning",
+                                     "sage_res_dropout", "gatenum_scale_dropout"])
+def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, variant):
+    """The row-sparse backward (kept-zero tables, row sets, gradient frontier, Linear backward on listed rows) is active
+    from 16 384 entity rows on -- sizes the reference-fixture tests do not reach.  Here every model family runs at 40 k
+    rows against ITSELF with the machinery off (zeros_like table, no row sets): training-mode dropout (the masks are
+    regenerated from the step's seed in the sparse backward too), gin's stacked sums, linear_gat, the gates, three
+    layers, the TransE form and the fine-tuning head."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e, dim = 40_000, 240_000, 64
+    h, t, r = make_kg(n, e, seed=13)
+    over = dict(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, aggregation_type="gcn",
+                kg_l2loss_lambda=1e-4, fine_tuning_l2loss_lambda=1e-4, device=gpu_device)
+    scoring, mode, train = "transr", "pre_training", False
+    if variant == "dropout_train":
+        over.update(mess_dropout=0.3); train = True
+    elif variant == "gin":
+        over.update(aggregation_type="gin", mlp_hidden_dim=48)
+    elif variant == "scale_gat_dim":
+        over.update(scale_gat_dim=96)
+    elif variant == "gatemul_3layers":
+        over.update(n_conv_layers=3, use_num_lit=True, use_txt_lit=True, txt_lit_dim=40)
+    elif variant == "transe":
+        over.update(relation_dim=dim * 3); scoring = "transe"
+    elif variant == "fine_tuning":
+        mode = "fine_tuning"
+    elif variant == "sage_res_dropout":
+        over.update(aggregation_type="graphsage", use_residual=True, mess_dropout=0.2); train = True
+    elif variant == "gatenum_scale_dropout":
+        over.update(use_num_lit=True, scale_gat_dim=80, mess_dropout=0.1); train = True
+    cfg = O.default_cfg(**over)
+    torch.manual_seed(5)
+    num = torch.rand(n, 2) if cfg.use_num_lit else None
+    txt = torch.randn(n, cfg.txt_lit_dim) if cfg.use_txt_lit else None
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), num, txt, scoring=scoring).to(gpu_device)
+    m.train(train)
+    bh, br, bp, bn = (torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 60, 3, seed=3))
+    args = (bh, br, bp, bn) if mode == "pre_training" else (bh, bp, bn)
+    ops._RowScratch._tables.clear()
+
+    def grads(sparse):
+        m.zero_grad(set_to_none=True)
+        m._table_grad_stays_inside = (lambda: m.gat_rows is None) if sparse else (lambda: False)
+        out = []
+        for step in range(2):                       # two steps: the second re-uses the kept-zero tables of the first
+            torch.manual_seed(100 + step)           # the dropout seeds follow torch's CPU generator
+            loss = m(*args, device=gpu_device, mode=mode)
+            loss.backward()
+            out.append(float(loss.detach()))
+        return out, {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    try:
+        (l1, got), (l0, want) = grads(True), grads(False)
+    finally:
+        del m._table_grad_stays_inside
+        ops._RowScratch._tables.clear()
+    assert l1 == l0 and all(np.isfinite(l1)), (l1, l0)
+    assert got.keys() == want.keys() and len(want) >= 4
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) <= 5e-5 * scale, k
+
+
 @pytest.mark.parametrize("d,n_w", [(64, 2), (256, 0), (100, 1), (512, 4)])
 def test_gate_backward_statistics_ride_along(ops, gpu_device, d, n_w):
     """lkg_gate_blend_bwd_stats_f32: the same three outputs as lkg_gate_blend_bwd_f32, and its column statistics (bias
