@@ -328,6 +328,15 @@ int lkg_check_grouped_i64(int64_t n, int32_t rows_per_group, const int64_t *h, c
 int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, int32_t n_seg, const int32_t *perm,
                           const int32_t *seg, int32_t *perm_out, int32_t *seg_out, void *stream);
 
+/* Caller-supplied row ids (the batch's h / pos_t / neg_t, model.py:366-372; head / tail ids of the scoring heads,
+ * model.py:473-477) before any kernel gathers or scatters through them: out[i] = ids[i] when lo <= ids[i] < hi, else
+ * lo (a valid row), and *n_bad (device int32, cleared here) = the number of ids outside the range.  The reference
+ * raises IndexError / a device-side assert for such an id (its embedding lookups are bounds-checked by ATen); here
+ * the kernels only ever see in-range ids and the host raises once it has read the counter (one call late, no sync
+ * inside the step).                                                                                              */
+int lkg_sanitize_ids_i64(int64_t n, const int64_t *ids, int64_t lo, int64_t hi, int64_t *out, int32_t *n_bad,
+                         void *stream);
+
 /* K5  row-wise epilogue of an aggregation layer (model.py:111, 161, 305):
  *   a   = leaky_relu(z, slope)                    (z = Linear output, n x d)
  *   y   = layer_norm(a) * gamma + beta            (eps)

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "lkg_dense_score_bwd_f32": [i64, i32, i32, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, vp, vp, vp, vp, i64, vp, i64,
                                 vp],
     "lkg_check_grouped_i64": [i64, i32, vp, vp, vp, vp, vp],
+    "lkg_sanitize_ids_i64": [i64, vp, i64, i64, vp, vp, vp],
     "lkg_expand_groups_i32": [i64, i32, i32, vp, vp, vp, vp, vp],
     "lkg_act_layernorm_fwd_f32": [i64, i32, vp, i64, f32, vp, vp, f32, vp, i64, vp, i64, f32, vp, vp, f32, u64, vp],
     "lkg_act_layernorm_bwd_f32": [i64, i32, vp, i64, f32, vp, vp, vp, i64, vp, vp, vp, i64, vp, i64, f32, vp, i64, vp,

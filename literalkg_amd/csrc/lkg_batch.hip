@@ -165,6 +165,20 @@ __global__ void check_grouped_kernel(long n, int k, const long *__restrict__ h, 
     if (m && (threadIdx.x & 63) == 0) atomicAdd(n_bad, (int)__popcll(m));
 }
 
+// out[i] = ids[i] when lo <= ids[i] < hi, else lo; *n_bad += the number of ids outside the range
+__global__ __launch_bounds__(256) void sanitize_ids_kernel(long n, const long *__restrict__ ids, long lo, long hi,
+                                                            long *__restrict__ out, int *__restrict__ n_bad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const long v = ids[i];
+        bad = v < lo || v >= hi;
+        out[i] = bad ? lo : v;
+    }
+    const unsigned long long m = __ballot(bad);   // taken by all lanes, before the divergent add
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(n_bad, (int)__popcll(m));
+}
+
 }  // namespace
 
 extern "C" int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, int32_t n_seg, const int32_t *perm,
@@ -176,6 +190,21 @@ extern "C" int lkg_expand_groups_i32(int64_t n_groups, int32_t rows_per_group, i
     hipLaunchKernelGGL(expand_groups_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (long)n_groups, rows_per_group, n_seg, perm, seg, perm_out, seg_out);
     LKG_CHECK_LAUNCH("lkg_expand_groups_i32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_sanitize_ids_i64(int64_t n, const int64_t *ids, int64_t lo, int64_t hi, int64_t *out, int32_t *n_bad,
+                                    void *stream) {
+    LKG_REQUIRE(n >= 0 && lo < hi, "lkg_sanitize_ids_i64: bad sizes");
+    LKG_REQUIRE(n_bad && (n == 0 || (ids && out)), "lkg_sanitize_ids_i64: null pointer");
+    if (hipMemsetAsync(n_bad, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+        lkg_set_error("lkg_sanitize_ids_i64: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    if (n == 0) return LKG_OK;
+    hipLaunchKernelGGL(sanitize_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n,
+                       (const long *)ids, (long)lo, (long)hi, (long *)out, n_bad);
+    LKG_CHECK_LAUNCH("lkg_sanitize_ids_i64");
     return LKG_OK;
 }
 

@@ -379,6 +379,9 @@ class LiteralKG(nn.Module):
     def calc_triplet_loss(self, h, r, pos_t, neg_t):
         # generate_kg_batch repeats every sampled (h, r, t+) pre_training_neg_rate times (dataloader.py:318-330): such
         # a batch projects h and t+ once per group.  Checked on the ids (any other batch takes the general path).
+        h, pos_t, neg_t = ops.checked_ids(self.n_entities, h, pos_t, neg_t)     # (out-of-range ids never reach a kernel)
+        if self.scoring == "transe":       # (the TransR form checks r while it groups the batch by relation)
+            (r,) = ops.checked_ids(self.n_relations, r, what="relation")
         check, k = None, int(self.pre_training_neg_rate)
         if self.scoring == "transr" and self.group_reuse and k >= self.group_reuse_min_rate:
             check = ops.GroupedCheck(h, r, pos_t, k)      # queued now, answered just before the loss (no idle device)
@@ -456,6 +459,7 @@ class LiteralKG(nn.Module):
 
     # ------------------------------------------------------------------ f1 heads
     def calc_score(self, head_ids, tail_ids):
+        head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
         emb, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
         return ops.gemm(ops.gather_rows(emb.detach(), head_ids), ops.gather_rows(emb.detach(), tail_ids),
                         trans_b=True)
@@ -480,6 +484,7 @@ class LiteralKG(nn.Module):
         """mode='mlp' (model.py:506-519): sigmoid(fc3(bn2(relu(fc2(bn1(relu(fc1([e_h | e_t])))))))) ."""
         if not hasattr(self, "fc1"):
             raise AttributeError("call initialize_MLP() first (model.py:499)")
+        head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
         self.gat_embed, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
         eh = pruned.gather_rows(self.gat_embed, head_ids)
         et = pruned.gather_rows(self.gat_embed, tail_ids)
@@ -509,6 +514,7 @@ class LiteralKG(nn.Module):
 
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
         """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
+        head_ids, tail_pos_ids, tail_neg_ids = ops.checked_ids(self.n_entities, head_ids, tail_pos_ids, tail_neg_ids)
         self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
             head_ids, tail_pos_ids, tail_neg_ids)
         return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda,

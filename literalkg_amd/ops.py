@@ -93,6 +93,28 @@ def check_deferred_errors():
     _Deferred.poll(wait=True)
 
 
+def checked_ids(n_rows: int, *id_lists: torch.Tensor, what: str = "entity"):
+    """The id lists a caller hands in (a batch's h / pos_t / neg_t, head / tail ids of the scoring heads) as int64 tensors
+    that are SAFE to gather and scatter through: an id outside [0, n_rows) is replaced by row 0 on the device and
+    counted; the count surfaces as an IndexError at the next poll (``check_deferred_errors()`` waits for it) -- the
+    reference's embedding lookup raises for such an id, a kernel of this library would read or add out of bounds."""
+    _need_gpu(*id_lists)
+    shapes = [tuple(i.shape) for i in id_lists]
+    flat = [_i64(i.reshape(-1)) for i in id_lists]
+    src = flat[0] if len(flat) == 1 else torch.cat(flat)
+    out = torch.empty_like(src)
+    bad = torch.empty(1, dtype=torch.int32, device=src.device)
+    N.call("lkg_sanitize_ids_i64", src.numel(), N.ptr(src), 0, int(n_rows), N.ptr(out), N.ptr(bad), _stream())
+    _Deferred.poll()
+    _Deferred.watch(bad, IndexError, "{n} " + what + f" id(s) outside [0, {int(n_rows)}) in the ids handed to the model "
+                    "(replaced by row 0 on the device; the results of that call are meaningless)")
+    res, o = [], 0
+    for sh, f in zip(shapes, flat):
+        res.append(out[o:o + f.numel()].view(sh))
+        o += f.numel()
+    return res
+
+
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,

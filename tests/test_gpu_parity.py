@@ -560,6 +560,60 @@ def test_out_of_range_relation_raises_one_call_later(ops, gpu_device):
     assert torch.isfinite(ok)
 
 
+@pytest.mark.parametrize("scoring", ["transr", "transe"])
+def test_out_of_range_entity_ids_never_reach_a_kernel(L, ops, O, gpu_device, scoring):
+    """An entity id outside [0, n_entities) in a batch (h / pos_t / neg_t), in the fine-tuning triples or in the head /
+    tail lists of calc_score is an IndexError in the reference (bounds-checked embedding lookup).  The HIP kernels would
+    gather and atomically add out of bounds: the model replaces such ids by row 0 on the device before any kernel uses
+    them (lkg_sanitize_ids_i64) and raises IndexError once the counter has been read -- forward AND backward run on safe
+    ids, nothing faults, the module stays usable."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, dim = 3000, 16
+    h, t, r = make_kg(n, 20_000, seed=3)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else 2 * dim, conv_dim=dim,
+                        n_conv_layers=1, device=gpu_device)
+    torch.manual_seed(0)
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), scoring=scoring).to(gpu_device)
+    bh, br, bp, bn = (torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 20, 3, seed=1))
+    ops.check_deferred_errors()
+    bad_h, bad_n = bh.clone(), bn.clone()
+    bad_h[3:6] = n + 10_000_000          # (a whole group: the layout check still sees groups)
+    bad_n[7] = -5
+
+    def surfaces(match, fn):
+        """the error is raised by a later poll inside the same call (the check kernel is long done by then) or, at the
+        latest, by check_deferred_errors() -- exactly once"""
+        with pytest.raises(IndexError, match=match):
+            fn()
+            torch.cuda.synchronize()
+            ops.check_deferred_errors()
+        ops.check_deferred_errors()
+
+    surfaces("4 entity id", lambda: m(bad_h, br, bp, bad_n, device=gpu_device, mode="pre_training").backward())
+    if scoring == "transe":              # relation ids of the TransE form go straight into its score kernel
+        bad_r = br.clone()
+        bad_r[0:3] = 16
+        surfaces("3 relation id", lambda: m(bh, bad_r, bp, bn, device=gpu_device, mode="pre_training").backward())
+    surfaces("3 entity id", lambda: m(bad_h, bp, bn, device=gpu_device, mode="fine_tuning").backward())
+    if scoring == "transr":
+        m.eval()
+        surfaces("2 entity id", lambda: m(torch.tensor([1, n, 5], device=gpu_device), torch.tensor([-1, 2], device=gpu_device),
+                                          device=gpu_device, mode="predict"))
+        m.train()
+    # forward AND backward on the sanitised ids (the scatter of the row gradients included): nothing faults
+    ops._Deferred.pending.clear()
+    m.zero_grad(set_to_none=True)
+    hs, ns = ops.checked_ids(n, bad_h, bad_n)
+    assert int(hs.max()) < n and int(ns.min()) >= 0 and int((hs != bad_h).sum()) == 3 and int((ns != bad_n).sum()) == 1
+    ops._Deferred.pending.clear()
+    m.zero_grad(set_to_none=True)
+    ok = m(bh, br, bp, bn, device=gpu_device, mode="pre_training")
+    ok.backward()
+    ops.check_deferred_errors()
+    assert torch.isfinite(ok) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 # ----------------------------------------------------------------------------- whole module vs golden
 def _build_model(L, gd, device, scoring):
     cfg = golden_cfg(gd)
