@@ -288,6 +288,10 @@ class LiteralKG(nn.Module):
             self.numerical_literals_embed = self.numerical_literals_embed.to(self.device)
         if a.use_txt_lit:
             self.text_literals_embed = self.text_literals_embed.to(self.device)
+        for name, lit, width in (("numerical_literals", self.numerical_literals_embed if a.use_num_lit else None, self.n_num_lit),
+                                 ("text_literals", self.text_literals_embed if a.use_txt_lit else None, self.n_txt_lit)):
+            if lit is not None and tuple(lit.shape) != (self.n_entities, width):     # (the gate reads them row for row)
+                raise ValueError(f"{name} has shape {tuple(lit.shape)}, expected ({self.n_entities}, {width})")
         return (self.numerical_literals_embed if a.use_num_lit else None,
                 self.text_literals_embed if a.use_txt_lit else None)
 
@@ -449,6 +453,11 @@ class LiteralKG(nn.Module):
         return g
 
     def update_attention(self, h_list, t_list, r_list, relations):
+        if relations is not None and any(not 0 <= int(x) < self.n_relations for x in relations):
+            raise IndexError(f"update_att: relation id outside [0, {self.n_relations}) in `relations` "
+                             "(relation_embed.weight[r_idx], model.py:441)")
+        if relations is None and r_list.is_cuda:      # (no list to filter by: every triple's relation id is used as it is)
+            (r_list,) = ops.checked_ids(self.n_relations, r_list, what="relation")
         g = self._structure_for(h_list, t_list, r_list, relations)
         val, _ = ops.edge_softmax(g, self.entity_embed.weight.detach(), self.relation_embed.weight.detach())
         new = torch.sparse_coo_tensor(g.coo_indices(), val, (self.n_entities, self.n_entities), is_coalesced=True)

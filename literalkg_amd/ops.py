@@ -135,6 +135,13 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
     d = x.shape[1]
     if out is None:
         out = torch.empty((n_rows, d), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n_rows, d) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError(f"spmm_raw: out must be a float32 {n_rows} x {d} tensor with unit column stride (got {tuple(out.shape)})")
+    if rowptr.numel() < n_rows + 1 or col.numel() != val.numel():
+        raise ValueError("spmm_raw: rowptr needs n_rows + 1 offsets, col and val one element per stored entry")
+    for name_, t_ in (("add_self", add_self), ("add2", add2)):
+        if t_ is not None and tuple(t_.shape) != (n_rows, d):
+            raise ValueError(f"spmm_raw: {name_} must be {n_rows} x {d} (got {tuple(t_.shape)})")
     if add_self is not None:
         add_self = _f32_rows(add_self)
     if add2 is not None:
@@ -164,6 +171,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         if beta != 0.0:
             raise ValueError("gemm: beta != 0 needs out")
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (m, n) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError(f"gemm: out must be a float32 {m} x {n} tensor with unit column stride (got {tuple(out.shape)})")
+    if bias is not None and bias.numel() != n:
+        raise ValueError(f"gemm: bias of {bias.numel()} elements for {n} output columns")
     if not trans_a and k > 0 and tall_ok(m, n, (k,), single_panel_too=tagged_rowmax(a) is not None):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
     if (trans_a and not trans_b and alpha == 1.0 and beta == 0.0 and bias is None and _WGRAD_ENGINE == "longk"
@@ -491,6 +502,10 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
         rowmax = rows_absmax(a_panels)          # (before any .contiguous(): the producers' tags live on these objects)
     a_panels = [_f32_rows(a) for a in a_panels]
     m = a_panels[0].shape[0]
+    if any(a.shape[0] != m for a in a_panels):
+        raise ValueError(f"gemm_tall: the K-panels have {[a.shape[0] for a in a_panels]} rows")
+    if rowmax.numel() != m:
+        raise ValueError(f"gemm_tall: {rowmax.numel()} row maxima for {m} rows")
     ks = [a.shape[1] for a in a_panels]
     n_groups = len(b_blocks)
     gate = gate_x is not None
@@ -509,6 +524,14 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
         if beta != 0.0:
             raise ValueError("gemm_tall: beta != 0 needs out")
         out = torch.empty((m, rows), dtype=torch.float32, device=a_panels[0].device)
+    elif tuple(out.shape) != (m, rows) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError(f"gemm_tall: out must be a float32 {m} x {rows} tensor with unit column stride (got {tuple(out.shape)})")
+    if bias is not None and bias.numel() != n:
+        raise ValueError(f"gemm_tall: bias of {bias.numel()} elements for {n} (stacked) output columns")
+    if gate and tuple(gate_x.shape) != (m, rows):
+        raise ValueError(f"gemm_tall: the gate's x must be {m} x {rows} (got {tuple(gate_x.shape)})")
+    if keep is not None and any(t_ is not None and (tuple(t_.shape) != (m, rows) or t_.stride(1) != 1) for t_ in keep):
+        raise ValueError("gemm_tall: the kept tanh(g) / sigmoid(z) buffers must match the output's shape")
     np_ = len(ks)
     a_ptr = (_C.c_void_p * np_)(*[a.data_ptr() for a in a_panels])
     a_ld = (_C.c_int64 * np_)(*[_ld(a) for a in a_panels])
@@ -541,6 +564,11 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
         raise ValueError("update_att adds entity and relation embeddings: embed_dim must equal relation_dim "
                          "(model.py:441)")
     row_hi = g.n if row_hi is None else row_hi
+    if ent.shape[0] != g.n or not 0 <= row_lo <= row_hi <= g.n:
+        raise ValueError(f"edge_softmax: entity table of {ent.shape[0]} rows / row range [{row_lo}, {row_hi}) for a structure "
+                         f"of {g.n} entities")
+    if out is not None and (out.numel() != g.nnz or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise ValueError(f"edge_softmax: out must be a contiguous float32 array of {g.nnz} values")
     long_rows = g.long_rows(False, row_lo, row_hi)
     val = out if out is not None else torch.empty(g.nnz, dtype=torch.float32, device=ent.device)
     logits = torch.empty(g.nnz, dtype=torch.float32, device=ent.device) if want_logits else None
@@ -573,6 +601,15 @@ def permute_values(val: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- K3/K4 aggregation
+def _check_table(ego: torch.Tensor, g: KGStructure, val: torch.Tensor):
+    """The kernels gather rows of ego through g's column ids: a table with fewer rows than the structure has entities
+    would be read out of bounds."""
+    if ego.dim() != 2 or ego.shape[0] != g.n:
+        raise ValueError(f"aggregate: the table has shape {tuple(ego.shape)}, the structure {g.n} entities")
+    if val.numel() != g.nnz:
+        raise ValueError(f"aggregate: {val.numel()} attention values for {g.nnz} stored entries")
+
+
 class _Aggregate(Function):
     """side = A @ ego over the CSR; backward A^T @ grad over the CSC (A carries no gradient,
     model.py:261)."""
@@ -580,6 +617,7 @@ class _Aggregate(Function):
     @staticmethod
     def forward(ctx, ego, g: KGStructure, val, val_t, plus_self):
         _need_gpu(ego, val)
+        _check_table(ego, g, val)
         ctx.g = g
         ctx.val_t = val_t
         ctx.plus_self = plus_self
@@ -631,6 +669,7 @@ class _AggregateKeep(Function):
     @staticmethod
     def forward(ctx, ego, g: KGStructure, val, val_t, plus_self, keep_dst):
         _need_gpu(ego, val)
+        _check_table(ego, g, val)
         ctx.g, ctx.val_t, ctx.plus_self = g, val_t, plus_self
         ctx.set_materialize_grads(False)
         copy = None
