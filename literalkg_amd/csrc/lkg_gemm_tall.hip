@@ -169,25 +169,21 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
 // subnormals for elements below 2^-17 of their row maximum) and  a'.b' = hi_a hi_b + hs_a mid_b + mid_a hs_b.  64
 // accumulator registers less per lane: three 4-wave workgroups (or two 8-wave ones) share a CU and their phases overlap.
 template <int BN, int EPI, bool ONE>
-// (the gate's x stash leaves room for ONE 256-column workgroup per CU whatever its registers: no reason to squeeze it)
-__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu((ONE && !(EPI == EPI_GATE && BN == 256)) ? (BN == 128 ? 3 : 4) : 2,
-                                                                      (ONE && !(EPI == EPI_GATE && BN == 256)) ? (BN == 128 ? 3 : 4) : 2)))
+__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(ONE ? (BN == 128 ? 3 : 4) : 2, ONE ? (BN == 128 ? 3 : 4) : 2)))
 void gemm_tall_kernel(TallArgs g) {
     constexpr int NT = 2 * BN;                    // threads
     constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
     constexpr int TPR = TK / EPT;                 // threads per A row
     constexpr int APL = TM * TK, BPL = BN * TK;   // halves per plane
     constexpr int BUF = 2 * APL + 2 * BPL;        // halves per buffer
-    // ONE dynamic LDS object: staging planes, the tile's row exponents, and (gate) the stash of the x values the blend
-    // needs -- x is the gate's first K-panel, so the columns of this tile pass through the staging registers anyway
+    // ONE dynamic LDS object: staging planes, the raw A ring, the tile's row / column exponents and bias (76 KB at BN = 256:
+    // two workgroups per CU, the gate's included)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     constexpr int RING = 3;                        // raw A tiles (f32, as loaded) in flight
     float *raw_s = reinterpret_cast<float *>(smem + 2 * BUF);
     int *ea_s = reinterpret_cast<int *>(raw_s + RING * TM * TK);
     int *eb_s = ea_s + TM;                         // exponents / bias of this tile's BN stacked columns: fetched at the start,
     float *bias_s = reinterpret_cast<float *>(eb_s + BN);   //   read in the epilogue without a global round trip
-    constexpr int XP = BN / 2 + 4;                 // stash pitch (floats): the tile's output columns + 4, conflict-free 16-byte writes
-    float *xstash = bias_s + BN;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / (BN / 64), wn = wave % (BN / 64);
@@ -307,12 +303,10 @@ void gemm_tall_kernel(TallArgs g) {
         __builtin_amdgcn_global_load_lds((gu4 *)(src + BPL / 8), (lds_void *)(d + BPL / 8), 16, 0, 0);
     };
     int st_k0 = 0, st_kp = 0;                      // the tile being staged: first k of this thread's windows, panel width
-    bool st_first = true;                          //   ... and whether it belongs to panel 0 (the gate's x)
     unsigned st_sh = 0;
     auto plan_stage = [&]() {
         st_k0 = s_tk * TK + akc * EPT;
         st_kp = s_kp;
-        st_first = s_panel == 0;
         st_sh = sh_fifo;
         sh_fifo >>= 4;
         if (s_gt + 1 < n_tiles) {                 // the same walk as plan_a's
@@ -382,15 +376,6 @@ void gemm_tall_kernel(TallArgs g) {
                 const int kk = st_k0 + 4 * q;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) e[4 * q + u] = kk + u < st_kp ? e[4 * q + u] : 0.f;
-            }
-            if constexpr (EPI == EPI_GATE) {      // keep x[rows of the tile, output columns of the tile] for the epilogue
-#pragma unroll
-                for (int q = 0; q < NA; ++q) {
-                    const int c = st_k0 + 4 * q - (n0 >> 1);
-                    if (st_first && c >= 0 && c < BN / 2)
-                        *reinterpret_cast<float4 *>(xstash + arow * XP + c) =
-                            make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
-                }
             }
         };
         auto p_hi = [&]() {
@@ -469,14 +454,6 @@ void gemm_tall_kernel(TallArgs g) {
             e[4 * q + 1] = kk + 1 < st_kp ? e1 : 0.f;
             e[4 * q + 2] = kk + 2 < st_kp ? e2 : 0.f;
             e[4 * q + 3] = kk + 3 < st_kp ? e3 : 0.f;
-        }
-        if constexpr (EPI == EPI_GATE) {
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int c = st_k0 + 4 * q - (n0 >> 1);
-                if (st_first && c >= 0 && c < BN / 2)
-                    *reinterpret_cast<float4 *>(xstash + arow * XP + c) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
-            }
         }
         _Float16 *pa = D + arow * TK + ((((akc * EPT) >> 3) ^ ((arow >> 4) & 1)) << 3) + ((akc * EPT) & 7);
 #pragma unroll
@@ -598,7 +575,12 @@ void gemm_tall_kernel(TallArgs g) {
                 const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
                 float xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xstash[(lr0 + (r & 3) + 8 * (r >> 2)) * XP + wn * 32 + (lane & 31)];
+                // x[rows of the tile, this lane's output column]: re-read (two 128-byte runs per instruction; +n d 4 bytes of traffic).
+                // Round 2 kept these values in a 66 KB LDS stash filled while the x panel was staged: one workgroup per CU
+                // then, and the k loop of a lone workgroup leaves the matrix pipe 38 % busy -- two per CU: GateMul forward
+                // 1 M x (256+2+300) 2.73 -> 2.46 ms, forward + backward 8.5 -> 7.9 ms.
+                for (int r = 0; r < 16; ++r)
+                    xv[r] = g.x[min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1) * g.ldx + cc];
                 float ov[16], gv[16], zv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -758,10 +740,10 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
-    auto lds_bytes = [](int bn_, bool gate) {
-        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4 + (gate ? TM * (bn_ / 2 + 4) * 4 : 0);
+    auto lds_bytes = [](int bn_) {
+        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4;
     };
-    const int lds = lds_bytes(bn, epilogue == EPI_GATE);
+    const int lds = lds_bytes(bn);
     const bool one = tall_variant() != 0;
 #define LKG_TALL_GO(BN_, EPI_, ONE_)                                                                                   \
     do {                                                                                                               \
