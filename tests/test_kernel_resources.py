@@ -26,3 +26,19 @@ def test_no_kernel_spills_or_uses_scratch(src):
     assert kernels and len(kernels) == len(spills) == len(scratch), (len(kernels), len(spills), len(scratch))
     bad = [(k, s, p) for k, s, p in zip(kernels, spills, scratch) if s or p]
     assert not bad, bad
+
+
+def test_tall_gemm_keeps_two_workgroups_per_cu():
+    """The one-accumulator 256-column tall kernels (plain AND gate epilogue) are built for two 8-wave workgroups per CU:
+    at most 128 VGPRs (4 waves per SIMD) -- with one workgroup per CU the k loop of the gate left the matrix pipe 38 %
+    busy.  Their LDS (76 KB each) is dynamic and set by the launcher."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", "-",
+                          os.path.join(CSRC, "lkg_gemm_tall.hip")], check=True, capture_output=True, text=True).stdout
+    found = {}
+    for name, vgpr in re.findall(r"\.name:\s+(\S*gemm_tall_kernelILi256ELi[01]ELb1E\S*)\n(?:.*\n)*?.*?\.vgpr_count:\s+(\d+)", asm):
+        found[name] = int(vgpr)
+    assert len(found) == 2, found
+    assert all(v <= 128 for v in found.values()), found
