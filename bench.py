@@ -196,9 +196,25 @@ def whole_path_timings(h, t, r, n, d, dev):
         gemm_ms = _timed(lambda: ops.gemm(ego, w, trans_b=True, bias=b, out=y))
         ops._ENGINE = ops_engine
         del y
+        # (iv) the attention refresh kernel alone (K1 + K2: per-edge logit, merge, row softmax) against the HBM roofline
+        g_att = att.graph
+        val_buf = torch.empty(g_att.nnz, dtype=torch.float32, device=dev)
+        rel_w = model.relation_embed.weight.detach()
+        att_ms = _timed(lambda: ops.edge_softmax(g_att, ego, rel_w, out=val_buf))
+        att_bytes = g_att.nnz * (4 * d + 12) + n * 4 * d + rel_w.shape[0] * 4 * d + 4 * (n + 1)
+        del val_buf
     flops = 2.0 * n * d * d
     e = len(h)
     out = {"config": f"LiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, same graph",
+           "roofline_attention": {"bound": "hbm", "kernel": "edge_softmax_kernel (lkg_edge_softmax_f32: logit + merge + row softmax, "
+                                                            "one launch)",
+                                  "algorithmic_bytes": att_bytes, "avg_launch_ms": att_ms,
+                                  "achieved": att_bytes / att_ms / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                  "frac": att_bytes / att_ms / 1e6 / HBM_PEAK_GBS,
+                                  "note": "one random WHOLE row (4 d bytes) gathered per stored entry from the entity table: the "
+                                          "access pattern MI355X_MICROARCH.md measures at 5.5-5.8 TB/s chip-wide; the SpMM "
+                                          "passes that ceiling with 128-column slabs, a dot product over the whole row cannot "
+                                          "(DESIGN.md section 9: two rewrites measured)"},
            "update_att_first_call_ms": upd_first,
            "update_att_ms": upd, "update_att_edges_per_s": e / upd * 1e3,
            "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
