@@ -342,6 +342,139 @@ __global__ __launch_bounds__(256) void act_ln_bwd_kernel(long n, int d, const fl
     }
 }
 
+// Backward over narrow rows (d <= 128 floats, 16-byte path, dense output: the layers BELOW the last one of a deep narrow
+// model -- the reference's default is eight layers of 32): LPR = 32 / 16 / 8 lanes per row, 64 / LPR rows per wave, like
+// act_ln_fwd_narrow_kernel.  Per-row conditions are per sub-group here, so every lane runs every reduction (the DPP
+// butterflies need all lanes) on masked values and only the stores are predicated.  y is required when g_yn is given
+// (the rows-only recompute of the last layer stays on act_ln_bwd_kernel).  Same arithmetic as act_ln_bwd_kernel<4, 1>;
+// g_gamma / g_beta partial sums meet across sub-groups by shuffles, across waves in LDS, one atomic per workgroup.
+template <int LPR>
+__global__ __launch_bounds__(256) void act_ln_bwd_narrow_kernel(long n, int d, const float *__restrict__ z, long ldz,
+                                                                 float slope, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ y, long ldy,
+                                                                 const float *__restrict__ save_mean,
+                                                                 const float *__restrict__ save_rstd,
+                                                                 const float *__restrict__ g_y, long ldgy,
+                                                                 const float *__restrict__ g_yn, long ldgyn, float norm_eps,
+                                                                 float *__restrict__ g_z, long ldgz,
+                                                                 float *__restrict__ g_gamma, float *__restrict__ g_beta,
+                                                                 float drop_p, unsigned long long seed,
+                                                                 float *__restrict__ gz_rowmax,
+                                                                 const unsigned char *__restrict__ gyn_rows) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red_g[3][4][LPR], red_b[3][4][LPR];
+    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    const int e = sl * 4;
+    const bool live = e < d;
+    const int ec = live ? e : 0;                 // (lanes past the width load the row's first chunk and drop it)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gam[4];
+    {
+        const float4 t = *reinterpret_cast<const float4 *>(gamma + ec);
+        gam[0] = live ? t.x : 0.f; gam[1] = live ? t.y : 0.f; gam[2] = live ? t.z : 0.f; gam[3] = live ? t.w : 0.f;
+    }
+    float acc_g[4] = {0.f, 0.f, 0.f, 0.f}, acc_b[4] = {0.f, 0.f, 0.f, 0.f};
+    const long n_groups = (n + RPW - 1) / RPW;
+    for (long it = wave; it < n_groups; it += nwaves) {
+        const long row_raw = it * RPW + sub;
+        const bool valid = row_raw < n;
+        const long row = valid ? row_raw : n - 1;
+        const bool has_gyn = g_yn && (!gyn_rows || gyn_rows[row]);
+        const bool any = valid && (g_y || has_gyn);          // does a gradient reach this row at all?
+        auto ld4 = [&](const float *base, long ld, bool on, float (&v)[4]) {
+            const float4 t = on ? *reinterpret_cast<const float4 *>(base + row * ld + ec) : zero4;
+            v[0] = (on && live) ? t.x : 0.f; v[1] = (on && live) ? t.y : 0.f;
+            v[2] = (on && live) ? t.z : 0.f; v[3] = (on && live) ? t.w : 0.f;
+        };
+        float zz[4], G[4];
+        ld4(z, ldz, any, zz);
+        ld4(g_y, ldgy, any && g_y != nullptr, G);
+        {
+            float yy[4], gn[4];
+            ld4(y, ldy, any && has_gyn, yy);
+            ld4(g_yn, ldgyn, any && has_gyn, gn);
+            float n2 = 0.f, dt = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                n2 = fmaf(yy[k], yy[k], n2);
+                dt = fmaf(yy[k], gn[k], dt);
+            }
+            const float nrm = sqrtf(group_sum<LPR>(n2));
+            dt = group_sum<LPR>(dt);
+            if (nrm > norm_eps) {                 // (rows without g_yn: yy = gn = 0, nrm = 0: the else branch adds zeros)
+                const float inv = 1.f / nrm;
+                const float proj = dt * inv * inv * inv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) G[k] += gn[k] * inv - yy[k] * proj;
+            } else {
+                const float inv = 1.f / norm_eps;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) G[k] += gn[k] * inv;
+            }
+        }
+        if (drop_p > 0.f) {
+            const float inv_keep = 1.f / (1.f - drop_p);
+            const unsigned rkey = drop_row_key(seed, (unsigned long long)row);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) G[k] *= drop_scale(rkey, (unsigned)(e + k), drop_p, inv_keep);
+        }
+        const float mean = save_mean[row], rstd = save_rstd[row];
+        float s1 = 0.f, s2 = 0.f, xh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = zz[k];
+            const float a = t > 0.f ? t : t * slope;
+            xh[k] = (any && live) ? (a - mean) * rstd : 0.f;
+            const float dx = G[k] * gam[k];
+            s1 += dx;
+            s2 = fmaf(dx, xh[k], s2);
+            acc_g[k] = fmaf(G[k], xh[k], acc_g[k]);
+            acc_b[k] += G[k];
+        }
+        s1 = group_sum<LPR>(s1) / (float)d;
+        s2 = group_sum<LPR>(s2) / (float)d;
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dx = G[k] * gam[k];
+            const float da = rstd * (dx - s1 - xh[k] * s2);
+            zz[k] = (any && live) ? da * (zz[k] > 0.f ? 1.f : slope) : 0.f;
+            mx = fmaxf(mx, fabsf(zz[k]));
+        }
+        if (valid && live) *reinterpret_cast<float4 *>(g_z + row * ldgz + e) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        if (gz_rowmax) {
+            mx = group_max<LPR>(mx);
+            if (valid && sl == 0) gz_rowmax[row] = mx;
+        }
+    }
+    // columns e .. e+3 are held by lane sl of every sub-group: fold the sub-groups, then the waves, then one atomic each
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) {
+            acc_g[k] += __shfl_xor(acc_g[k], m, 64);
+            acc_b[k] += __shfl_xor(acc_b[k], m, 64);
+        }
+    const int w = threadIdx.x >> 6;
+    if (w > 0 && sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red_g[w - 1][k][sl] = acc_g[k];
+            red_b[w - 1][k][sl] = acc_b[k];
+        }
+    }
+    __syncthreads();
+    if (w == 0 && sub == 0 && live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(g_gamma + e + k, acc_g[k] + red_g[0][k][sl] + red_g[1][k][sl] + red_g[2][k][sl]);
+            atomicAdd(g_beta + e + k, acc_b[k] + red_b[0][k][sl] + red_b[1][k][sl] + red_b[2][k][sl]);
+        }
+    }
+}
+
 // Literal-gate blend: rows are walked by groups of TPR = 2^k threads (TPR * W >= d when possible), so the
 // (row, column) of an element needs shifts only and every access is a 16-byte one when rows are aligned.
 template <int W>
@@ -661,6 +794,21 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
                      (!g_yn || (ldgyn % 4 == 0 && (!y || ldy % 4 == 0))) && lkg_aligned16(z) && lkg_aligned16(g_z) &&
                      lkg_aligned16(gamma) && (!g_y || lkg_aligned16(g_y)) &&
                      (!g_yn || (lkg_aligned16(g_yn) && (!y || lkg_aligned16(y)) && (y || lkg_aligned16(beta))));
+    if (vec && d <= 128 && !sparse_out && !row_ids && (!g_yn || y) && n >= 4096) {      // several rows per wave
+        const int lpr = d <= 32 ? 8 : d <= 64 ? 16 : 32;
+        const int64_t groups = (n + 64 / lpr - 1) / (64 / lpr);
+        const dim3 grid_n((unsigned)std::min<int64_t>((groups + 3) / 4, 2048));
+#define LKG_NARROW(LPR_)                                                                                                   \
+    hipLaunchKernelGGL((act_ln_bwd_narrow_kernel<LPR_>), grid_n, dim3(256), 0, s, (long)n, d, z, (long)ldz, slope, gamma, y,   \
+                       (long)ldy, save_mean, save_rstd, g_y, (long)ldgy, g_yn, (long)ldgyn, norm_eps, g_z, (long)ldgz, g_gamma, \
+                       g_beta, drop_p, (unsigned long long)seed, g_z_rowmax, g_yn ? g_yn_rows : nullptr)
+        if (lpr == 8) LKG_NARROW(8);
+        else if (lpr == 16) LKG_NARROW(16);
+        else LKG_NARROW(32);
+#undef LKG_NARROW
+        LKG_CHECK_LAUNCH("lkg_act_layernorm_bwd_f32");
+        return LKG_OK;
+    }
     const int64_t n_work = row_ids ? n_row_ids : n;
     if (n_work == 0) return LKG_OK;
     const dim3 grid((unsigned)std::min<int64_t>((n_work + 3) / 4, 1024));

@@ -398,12 +398,13 @@ def test_gemm_split_k_and_slices(ops, gpu_device):
 
 
 # ----------------------------------------------------------------------------- K5 / K6 epilogues
-@pytest.mark.parametrize("d", [8, 30, 32, 64, 100, 128, 132, 256, 300, 1024])
+@pytest.mark.parametrize("d,n", [(8, 257), (30, 257), (32, 257), (64, 257), (100, 257), (128, 257), (132, 257), (256, 257),
+                                 (300, 257), (1024, 257),
+                                 (8, 5001), (32, 5001), (64, 5001), (100, 5001), (128, 5001)])      # several rows per wave, both ways
 @pytest.mark.parametrize("with_norm", [True, False])
-def test_act_layernorm(ops, gpu_device, d, with_norm):
+def test_act_layernorm(ops, gpu_device, d, n, with_norm):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(d)
-    n = 257
     z = torch.randn(n, d, generator=gen)
     gamma, beta = torch.randn(d, generator=gen), torch.randn(d, generator=gen)
     wy, wn = torch.randn(n, d, generator=gen), torch.randn(n, d, generator=gen)
@@ -712,7 +713,7 @@ def test_fused_dropout_forward_backward(ops, gpu_device, p):
     1-p, kept values are LN/(1-p), and the backward equals autograd through the same explicit mask."""
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(1)
-    n, d = 4000, 64
+    n, d = 6000, 64                     # (narrow rows, several per wave, in both directions)
     z = torch.randn(n, d, generator=gen).to(gpu_device)
     gamma, beta = torch.randn(d, generator=gen).to(gpu_device), torch.randn(d, generator=gen).to(gpu_device)
     wy, wn = torch.randn(n, d, generator=gen).to(gpu_device), torch.randn(n, d, generator=gen).to(gpu_device)
@@ -1064,12 +1065,23 @@ def test_device_entry_points_reject_bad_arguments(L, ops, gpu_device):
     ("bi-interaction", 1, 50, "num", None, "transe"),
 ])
 def test_module_matches_oracle_at_realistic_widths(L, O, gpu_device, agg, layers, dim, gate, scale, scoring):
+    _module_against_oracle(L, O, gpu_device, agg, layers, dim, dim, gate, scale, scoring)
+
+
+def test_module_matches_oracle_at_the_reference_default_architecture(L, O, gpu_device):
+    """argument_pretraining.py's defaults (lines 34-62): embed_dim = relation_dim = scale_gat_dim = 300, EIGHT gcn layers of
+    conv_dim 32 (concatenated width 300 + 8 * 32 = 556 -> linear_gat -> 300), GateMul over 2 numeric + 300 text literals,
+    TransR with a 300 x 300 matrix per relation -- what a user of the reference runs when no flag is given."""
+    _module_against_oracle(L, O, gpu_device, "gcn", 8, 300, 32, "mul", 300, "transr")
+
+
+def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, scale, scoring):
     from literalkg_amd.synth import make_batch, make_kg
     from literalkg_amd import io
     n, e = 20_000, 150_000
     h, t, r = make_kg(n, e, seed=5)
-    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else (scale or dim * (layers + 1)),
-                        conv_dim=dim, n_conv_layers=layers, aggregation_type=agg, scale_gat_dim=scale,
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else (scale or dim + conv_dim * layers),
+                        conv_dim=conv_dim, n_conv_layers=layers, aggregation_type=agg, scale_gat_dim=scale,
                         use_num_lit=gate in ("mul", "num"), use_txt_lit=gate in ("mul", "txt"),
                         txt_lit_dim=300 if dim % 4 == 0 else 7,
                         mlp_hidden_dim=48, kg_l2loss_lambda=1e-4, device=gpu_device)

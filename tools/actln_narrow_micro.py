@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""act_ln forward at narrow widths (several rows per wave) against the bytes it moves (GPU box only; tuning aid)."""
+"""act_ln forward / backward at narrow widths (several rows per wave) against the bytes they move (GPU box only; tuning aid)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,4 +22,9 @@ for d in (32, 64, 128, 256):
     for drop in (0.0, 0.1):
         t = timeit(lambda: ops._ActLayerNorm.apply(z, gamma, beta, True, 0.01, 1e-5, 1e-12, drop, 7, None, True))
         t2 = timeit(lambda: ops._ActLayerNorm.apply(z, gamma, beta, True, 0.01, 1e-5, 1e-12, drop, 7, None, False))
-        print(f"d={d:4d} drop={drop}: y+yn {t:.3f} ms {3*gb/t*1e3:.0f} GB/s | yn only {t2:.3f} ms {2*gb/t2*1e3:.0f} GB/s")
+        print(f"d={d:4d} drop={drop}: fwd y+yn {t:.3f} ms {3*gb/t*1e3:.0f} GB/s | yn only {t2:.3f} ms {2*gb/t2*1e3:.0f} GB/s")
+    zg = z.clone().requires_grad_(True)
+    y, yn = ops.act_layernorm(zg, gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), want_norm=True, drop_p=0.1, seed=5)
+    gy, gyn = torch.randn(n, d, device=dev), torch.randn(n, d, device=dev)
+    t = timeit(lambda: torch.autograd.grad([y, yn], zg, [gy, gyn], retain_graph=True))
+    print(f"d={d:4d} bwd (g_y + g_yn, dropout): {t:.3f} ms {6*gb/t*1e3:.0f} GB/s")

@@ -22,6 +22,10 @@ ap.add_argument("--e", type=int, default=10_000_000)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfgs = {
+    # the reference's DEFAULT architecture (argument_pretraining.py:34-62): 300-wide embeddings, eight gcn layers of 32, GateMul,
+    # linear_gat 556 -> 300, TransR 300 x 300 per relation
+    "default": dict(embed_dim=300, relation_dim=300, conv_dim=32, n_conv_layers=8, use_num_lit=True, use_txt_lit=True,
+                    scale_gat_dim=300, mess_dropout=0.1),
     # BASELINE config[0]'s shape (data/Small; run with --n 765957 --e 252000): the launch-bound end of the range
     "c1": dict(embed_dim=64, relation_dim=64, conv_dim=64, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
     "c2": dict(embed_dim=128, relation_dim=128, conv_dim=128, n_conv_layers=1, use_num_lit=False, use_txt_lit=False),
