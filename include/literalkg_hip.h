@@ -418,6 +418,14 @@ int lkg_gemm_wgrad_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t 
 int lkg_gemm_longk_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
 int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
                        float *c, int64_t ldc, void *stream);
+/* The same product for a NARROW A (m <= 64: dW = dY^T X of an aggregation layer whose conv_dim is 32 or 64 -- the
+ * reference's default stacks eight layers of 32, argument_pretraining.py:54-58): exact f32 FMAs on the VALU over LDS-staged
+ * 32-row tiles, every thread an (m / 16) x 4 block of a 64-column chunk of C, slices of k combined by f32 atomics -- the
+ * matrix-core engines would spend a 256 x 128 tile on it.  lkg_gemm_smallm_ok: m <= 64, k >= 4096, widths and strides
+ * multiples of 4 floats, 16-byte aligned operands.  C is overwritten.                                                  */
+int lkg_gemm_smallm_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
+int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                        float *c, int64_t ldc, void *stream);
 /* out[c] = max_r |x[r,c]|  (out is overwritten)                                                     */
 int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 

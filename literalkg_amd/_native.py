@@ -70,6 +70,8 @@ PROTOTYPES = {
     "lkg_col_absmax_f32": [i64, i32, vp, i64, vp, vp],
     "lkg_gemm_longk_ok": [i64, i64, i64, vp, i64, vp, i64],
     "lkg_gemm_longk_f32": [i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
+    "lkg_gemm_smallm_ok": [i64, i64, i64, vp, i64, vp, i64],
+    "lkg_gemm_smallm_f32": [i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_wgrad_f32": [i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp],
     "lkg_colsum_weighted_f32": [i64, i32, vp, i64, vp, i64, i32, vp, vp, i64, vp],
     "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],

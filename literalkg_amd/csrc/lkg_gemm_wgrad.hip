@@ -707,3 +707,120 @@ extern "C" int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *
                 "row strides that are multiples of 4 floats and 16-byte aligned operands (lkg_gemm_longk_ok)");
     return longk_launch(false, m, n, k, a, lda, nullptr, b, ldb, nullptr, c, ldc, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients with a NARROW dY: C[m, n] = sum over the k rows of A[k, m] * B[k, n] for m <= 64 (an aggregation
+// layer of conv_dim 32 -- the reference's default is eight of them, argument_pretraining.py:54-58 -- has dW = dY^T X
+// with dY 32 wide).  The matrix-core engines above spend a 256 x 128 (or 128 x 128) tile on it: 0.7 ms for a 32 x 32
+// product over 1 M rows that moves 256 MB.  Here the product is plain f32 FMAs on the VALU: a workgroup walks its
+// slice of the k rows in tiles of 32 rows staged in LDS, every thread keeps an (MT / 16) x 4 block of the MT x 64
+// output chunk in registers (two LDS reads per row and thread, 16-byte, conflict-free), the slices are combined by f32
+// atomics into the zeroed output.  n is covered in chunks of 64 columns (grid.y).  Exact f32 products, f32 sums.
+namespace {
+
+template <int MT>
+__global__ __launch_bounds__(256) void smallm_wgrad_kernel(long m, long n, long k, const float *__restrict__ a, long lda,
+                                                            const float *__restrict__ b, long ldb, float *__restrict__ c,
+                                                            long ldc, long rows_per_block) {
+    constexpr int RM_ = MT / 16;                   // output rows per thread (2 or 4)
+    constexpr int R = 32;                          // k rows per staged tile
+    __shared__ __attribute__((aligned(16))) float as[R][MT], bs[R][64];
+    const int t = threadIdx.x;
+    const int bi = t >> 4, bj = t & 15;            // output block: rows RM_ * bi .., columns 4 * bj .. of this chunk
+    const long n0 = (long)blockIdx.y * 64;
+    const long k_lo = (long)blockIdx.x * rows_per_block, k_hi = min(k, k_lo + rows_per_block);
+    if (k_lo >= k_hi) return;
+    float acc[RM_][4];
+#pragma unroll
+    for (int i = 0; i < RM_; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // staging: the A tile is R x MT floats = R * MT / 4 16-byte pieces, the B tile R x 64 = 512 pieces (2 per thread)
+    constexpr int APIECES = R * MT / 4, A_PER_ROW = MT / 4;
+    for (long k0 = k_lo; k0 < k_hi; k0 += R) {
+#pragma unroll
+        for (int p = t; p < APIECES; p += 256) {
+            const int r = p / A_PER_ROW, cq = (p % A_PER_ROW) * 4;
+            const long row = min(k0 + r, k_hi - 1);
+            const bool on = k0 + r < k_hi && cq < m;               // (m, n are multiples of 4: a piece is in or out)
+            const float4 v = *reinterpret_cast<const float4 *>(a + row * lda + (cq < m ? cq : 0));
+            *reinterpret_cast<float4 *>(&as[r][cq]) = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = t; p < R * 16; p += 256) {
+            const int r = p >> 4, cq = (p & 15) * 4;
+            const long row = min(k0 + r, k_hi - 1);
+            const bool on = k0 + r < k_hi && n0 + cq < n;
+            const float4 v = *reinterpret_cast<const float4 *>(b + row * ldb + (n0 + cq < n ? n0 + cq : 0));
+            *reinterpret_cast<float4 *>(&bs[r][cq]) = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) {
+            const float4 bv = *reinterpret_cast<const float4 *>(&bs[r][4 * bj]);
+            float av[RM_];
+            if constexpr (RM_ == 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(&as[r][4 * bi]);
+                av[0] = x.x; av[1] = x.y; av[2] = x.z; av[3] = x.w;
+            } else {
+                const float2 x = *reinterpret_cast<const float2 *>(&as[r][2 * bi]);
+                av[0] = x.x; av[1] = x.y;
+            }
+#pragma unroll
+            for (int i = 0; i < RM_; ++i) {
+                acc[i][0] = fmaf(av[i], bv.x, acc[i][0]);
+                acc[i][1] = fmaf(av[i], bv.y, acc[i][1]);
+                acc[i][2] = fmaf(av[i], bv.z, acc[i][2]);
+                acc[i][3] = fmaf(av[i], bv.w, acc[i][3]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RM_; ++i) {
+        const long row = RM_ * bi + i;
+        if (row >= m) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long col = n0 + 4 * bj + j;
+            if (col < n) atomicAdd(c + row * ldc + col, acc[i][j]);
+        }
+    }
+}
+
+}  // namespace
+
+// 1 when lkg_gemm_smallm_f32 takes this product: a narrow A (m <= 64) over many rows, widths and row strides multiples of
+// 4 floats, 16-byte aligned operands
+extern "C" int lkg_gemm_smallm_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb) {
+    return k >= 4096 && m >= 4 && m <= 64 && n >= 4 && m % 4 == 0 && n % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+           lkg_aligned16(a) && lkg_aligned16(b);
+}
+
+extern "C" int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                                   float *c, int64_t ldc, void *stream) {
+    LKG_REQUIRE(m > 0 && n > 0 && k > 0 && a && b && c && ldc >= n && lda >= m && ldb >= n, "lkg_gemm_smallm_f32: bad arguments");
+    LKG_REQUIRE(lkg_gemm_smallm_ok(m, n, k, a, lda, b, ldb), "lkg_gemm_smallm_f32: needs m <= 64, k >= 4096, widths and row "
+                "strides that are multiples of 4 floats and 16-byte aligned operands (lkg_gemm_smallm_ok)");
+    hipStream_t s = (hipStream_t)stream;
+    const hipError_t rc = ldc == n ? hipMemsetAsync(c, 0, sizeof(float) * m * n, s)
+                                   : hipMemset2DAsync(c, sizeof(float) * ldc, 0, sizeof(float) * n, m, s);
+    if (rc != hipSuccess) {
+        lkg_set_error("lkg_gemm_smallm_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    const int64_t chunks = (n + 63) / 64;
+    // about 8 workgroups per CU over the whole grid, slices of whole 32-row tiles, at least 256 rows each
+    int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2048 / chunks + 1, k / 256));
+    int64_t per = ((k + blocks - 1) / blocks + 31) / 32 * 32;
+    blocks = (k + per - 1) / per;
+    const dim3 grid((unsigned)blocks, (unsigned)chunks);
+    if (m <= 32)
+        hipLaunchKernelGGL((smallm_wgrad_kernel<32>), grid, dim3(256), 0, s, (long)m, (long)n, (long)k, a, (long)lda, b, (long)ldb,
+                           c, (long)ldc, (long)per);
+    else
+        hipLaunchKernelGGL((smallm_wgrad_kernel<64>), grid, dim3(256), 0, s, (long)m, (long)n, (long)k, a, (long)lda, b, (long)ldb,
+                           c, (long)ldc, (long)per);
+    LKG_CHECK_LAUNCH("lkg_gemm_smallm_f32");
+    return LKG_OK;
+}

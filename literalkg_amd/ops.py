@@ -178,6 +178,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     if not trans_a and k > 0 and tall_ok(m, n, (k,), single_panel_too=tagged_rowmax(a) is not None):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
     if (trans_a and not trans_b and alpha == 1.0 and beta == 0.0 and bias is None and _WGRAD_ENGINE == "longk"
+            and N.load().lkg_gemm_smallm_ok(m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b))):
+        # a narrow dY (conv_dim 32 / 64) over many rows: exact f32 on the VALU instead of a mostly empty matrix-core tile
+        N.call("lkg_gemm_smallm_f32", m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), N.ptr(out), _ld(out), _stream())
+        return out
+    if (trans_a and not trans_b and alpha == 1.0 and beta == 0.0 and bias is None and _WGRAD_ENGINE == "longk"
             and N.load().lkg_gemm_longk_ok(m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b))):
         # weight gradients (a^T @ b over millions of rows): the 256 x 128 engine with three tiles in flight
         N.call("lkg_gemm_longk_f32", m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), N.ptr(out), _ld(out), _stream())
@@ -821,8 +826,9 @@ class _Axpby(Function):
     @staticmethod
     def backward(ctx, g):
         alpha, beta, has_b = ctx.ab
-        ga = _elt(0, g, None, alpha, 0.0) if ctx.needs_input_grad[0] else None
-        gb = _elt(0, g, None, beta, 0.0) if has_b and ctx.needs_input_grad[1] else None
+        rows = tagged_rows(g)            # (element-wise: a gradient that is zero outside a row set stays zero outside it)
+        ga = tag_rows(_elt(0, g, None, alpha, 0.0), rows) if ctx.needs_input_grad[0] else None
+        gb = tag_rows(_elt(0, g, None, beta, 0.0), rows) if has_b and ctx.needs_input_grad[1] else None
         return ga, gb, None, None
 
 
@@ -840,8 +846,9 @@ class _Mul(Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        return (_elt(1, g, b) if ctx.needs_input_grad[0] else None,
-                _elt(1, g, a) if ctx.needs_input_grad[1] else None)
+        rows = tagged_rows(g)
+        return (tag_rows(_elt(1, g, b), rows) if ctx.needs_input_grad[0] else None,
+                tag_rows(_elt(1, g, a), rows) if ctx.needs_input_grad[1] else None)
 
 
 def mul(a, b):
@@ -861,8 +868,11 @@ class _LeakySum(Function):
     @staticmethod
     def backward(ctx, g):
         saved = ctx.saved_tensors
-        ga = _elt(3, g, saved[0], ctx.slope) if ctx.needs_input_grad[0] else None
-        gb = _elt(3, g, saved[1], ctx.slope) if len(saved) > 1 and ctx.needs_input_grad[1] else None
+        # the LeakyReLU behind linear_gat (model.py:310) sits between the loss and the whole encoder: the loss's gradient is
+        # zero outside <= 3B rows and so is this one -- the row set travels on, or everything below would run dense
+        rows = tagged_rows(g)
+        ga = tag_rows(_elt(3, g, saved[0], ctx.slope), rows) if ctx.needs_input_grad[0] else None
+        gb = tag_rows(_elt(3, g, saved[1], ctx.slope), rows) if len(saved) > 1 and ctx.needs_input_grad[1] else None
         return ga, gb, None
 
 

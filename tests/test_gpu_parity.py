@@ -1654,6 +1654,26 @@ def test_last_layer_backward_on_the_listed_rows_equals_the_dense_backward(ops, g
     assert float(res[1][0][flags == 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 32, 100_000), (32, 300, 50_001), (64, 64, 20_000), (16, 8, 4096), (48, 132, 9_999),
+                                   (64, 556, 30_000)])
+def test_narrow_weight_gradient_on_the_valu(ops, gpu_device, m, n, k):
+    """lkg_gemm_smallm_f32 (dW = dY^T X for a dY of <= 64 columns: exact f32 FMAs over LDS-staged row tiles, slices of k
+    combined by atomics) against f64, through ops.gemm(trans_a=True) -- contiguous operands and column slices of wider
+    tables (a CatBuffer slot), row counts that are not whole tiles."""
+    from literalkg_amd import _native as N
+    torch.manual_seed(m * n)
+    wide_a = torch.randn(k, m + 8, device=gpu_device)
+    wide_b = torch.randn(k, n + 12, device=gpu_device)
+    for a, b in ((wide_a[:, :m].contiguous(), wide_b[:, :n].contiguous()), (wide_a[:, 4:4 + m], wide_b[:, 8:8 + n])):
+        assert N.load().lkg_gemm_smallm_ok(m, n, k, N.ptr(a), ops._ld(a), N.ptr(b), ops._ld(b))
+        got = ops.gemm(a, b, trans_a=True).double()
+        want = a.double().t() @ b.double()
+        scale = a.double().abs().t() @ b.double().abs() + 1e-300
+        ref32 = (a.t() @ b).double()
+        e_got, e_f32 = float(((got - want).abs() / scale).max()), float(((ref32 - want).abs() / scale).max())
+        assert e_got <= max(2 * e_f32, 3e-7), (e_got, e_f32)
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 256, 40_000), (512, 300, 33_333), (64, 2, 5000), (130, 257, 16 * 700 + 5)])
 def test_weight_gradient_f16x2_engine_is_f32_accurate(ops, gpu_device, m, n, k):
     """lkg_gemm_wgrad_f32 (column-scaled exact fp16 hi/mid split, 3 MFMAs per product) against f64: within 3x of an f32
