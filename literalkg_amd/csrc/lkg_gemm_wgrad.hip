@@ -20,6 +20,7 @@
 // step (barrier -> split + write tile t+1 -> re-issue the loads of tile t+2 -> 12 MFMAs of tile t), split-K over the
 // grid with f32 atomics into the zeroed output.  32 KB of LDS (two fp16 planes per operand and buffer).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "lkg_common.h"
@@ -735,26 +736,47 @@ __global__ __launch_bounds__(256) void smallm_wgrad_kernel(long m, long n, long 
     for (int i = 0; i < RM_; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    // staging: the A tile is R x MT floats = R * MT / 4 16-byte pieces, the B tile R x 64 = 512 pieces (2 per thread)
-    constexpr int APIECES = R * MT / 4, A_PER_ROW = MT / 4;
-    for (long k0 = k_lo; k0 < k_hi; k0 += R) {
+    // staging: the A tile is R x MT floats = R * MT / 4 16-byte pieces (1 or 2 per thread), the B tile R x 64 = 512 pieces
+    // (2 per thread).  The pieces of tile t+1 are loaded into registers BEFORE tile t is multiplied and written to LDS
+    // after it: the global round trip runs behind the FMAs.
+    constexpr int APIECES = R * MT / 4, A_PER_ROW = MT / 4, NA = APIECES / 256, NB = 2;
+    float4 ra[NA], rb[NB];
+    auto load_tile = [&](long k0) {
 #pragma unroll
-        for (int p = t; p < APIECES; p += 256) {
-            const int r = p / A_PER_ROW, cq = (p % A_PER_ROW) * 4;
+        for (int q = 0; q < NA; ++q) {
+            const int p = t + 256 * q, r = p / A_PER_ROW, cq = (p % A_PER_ROW) * 4;
             const long row = min(k0 + r, k_hi - 1);
             const bool on = k0 + r < k_hi && cq < m;               // (m, n are multiples of 4: a piece is in or out)
             const float4 v = *reinterpret_cast<const float4 *>(a + row * lda + (cq < m ? cq : 0));
-            *reinterpret_cast<float4 *>(&as[r][cq]) = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[q] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int p = t; p < R * 16; p += 256) {
-            const int r = p >> 4, cq = (p & 15) * 4;
+        for (int q = 0; q < NB; ++q) {
+            const int p = t + 256 * q, r = p >> 4, cq = (p & 15) * 4;
             const long row = min(k0 + r, k_hi - 1);
             const bool on = k0 + r < k_hi && n0 + cq < n;
             const float4 v = *reinterpret_cast<const float4 *>(b + row * ldb + (n0 + cq < n ? n0 + cq : 0));
-            *reinterpret_cast<float4 *>(&bs[r][cq]) = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int p = t + 256 * q;
+            *reinterpret_cast<float4 *>(&as[p / A_PER_ROW][(p % A_PER_ROW) * 4]) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int p = t + 256 * q;
+            *reinterpret_cast<float4 *>(&bs[p >> 4][(p & 15) * 4]) = rb[q];
+        }
+    };
+    load_tile(k_lo);
+    store_tile();
+    __syncthreads();
+    for (long k0 = k_lo; k0 < k_hi; k0 += R) {
+        const bool more = k0 + R < k_hi;           // (workgroup-uniform)
+        if (more) load_tile(k0 + R);
 #pragma unroll 8
         for (int r = 0; r < R; ++r) {
             const float4 bv = *reinterpret_cast<const float4 *>(&bs[r][4 * bj]);
@@ -774,6 +796,8 @@ __global__ __launch_bounds__(256) void smallm_wgrad_kernel(long m, long n, long 
                 acc[i][3] = fmaf(av[i], bv.w, acc[i][3]);
             }
         }
+        __syncthreads();
+        if (more) store_tile();
         __syncthreads();
     }
 #pragma unroll
@@ -810,8 +834,11 @@ extern "C" int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float 
         return LKG_ERR_HIP;
     }
     const int64_t chunks = (n + 63) / 64;
-    // about 8 workgroups per CU over the whole grid, slices of whole 32-row tiles, at least 256 rows each
-    int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2048 / chunks + 1, k / 256));
+    // slices of whole 32-row tiles, at least 256 rows each; every slice ends in m x 64 atomics on the same few KB of C
+    // (contended float atomics run an order of magnitude below the streaming rate), so fewer and longer slices than the
+    // CUs could hold: LKG_SMALLM_BLOCKS (tuning aid) or 768 over the grid
+    static const int64_t target = getenv("LKG_SMALLM_BLOCKS") ? atoll(getenv("LKG_SMALLM_BLOCKS")) : 768;
+    int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(target / chunks + 1, k / 256));
     int64_t per = ((k + blocks - 1) / blocks + 31) / 32 * 32;
     blocks = (k + per - 1) / per;
     const dim3 grid((unsigned)blocks, (unsigned)chunks);

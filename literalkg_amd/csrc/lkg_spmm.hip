@@ -396,15 +396,19 @@ __global__ __launch_bounds__(256) void spmm_csr_grouped_kernel(int n_rows, int n
             for (int u = 0; u < U; ++u) ops::fma(acc, vv[u], xv[u]);
         }
     }
-    if (mine && (FULL || sl < nchunk)) {
+    const bool writes = mine && (FULL || sl < nchunk);
+    if (writes) {
         if (len == 0) acc = ops::zero();   // an empty row is exactly 0 (0 * Inf/NaN of the spare gathers must not leak)
         if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + (long)row * ld_self)[sl]);
         if (const float *a2 = ex.add2_row(row)) ops::fma(acc, 1.f, reinterpret_cast<const V *>(a2)[sl]);
         reinterpret_cast<V *>(out + (long)row * ldo)[sl] = acc;
-        if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(acc)));
         if (ex.copy_dst)
             reinterpret_cast<V *>(ex.copy_dst + (long)row * ex.ld_copy_dst)[sl] =
                 reinterpret_cast<const V *>(ex.copy_src + (long)row * ex.ld_copy_src)[sl];
+    }
+    if (ex.rowmax) {       // (wave-uniform: every lane is here)  ONE atomic per row: the LPE lanes of a row meet first -- an
+        const float rm = group_max<LPE>(writes ? ops::absmax(acc) : 0.f);   // atomic per lane cost the forward launches of
+        if (mine && sl == 0) atomicMax(ex.rowmax + row, __float_as_int(rm));   // 32-wide layers 0.3 ms each (0.55 vs 0.23 ms)
     }
 }
 
