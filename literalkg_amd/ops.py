@@ -871,6 +871,23 @@ class _LeakySum(Function):
         # the LeakyReLU behind linear_gat (model.py:310) sits between the loss and the whole encoder: the loss's gradient is
         # zero outside <= 3B rows and so is this one -- the row set travels on, or everything below would run dense
         rows = tagged_rows(g)
+        if rows_worth_compacting(rows, g.shape[0]):
+            # ... and only the listed rows are computed (gathered, passed through LeakyReLU', scattered into a table that is
+            # kept all-zero elsewhere) instead of a pass over all N rows
+            ids = rows.compact_ids()
+            n_rows, d = g.shape
+            gc = gather_rows_range(g, ids, 0, n_rows)
+            outs = []
+            for i in range(len(saved)):
+                if not ctx.needs_input_grad[i]:
+                    outs.append(None)
+                    continue
+                part = _elt(3, gc, gather_rows_range(saved[i], ids, 0, n_rows), ctx.slope)
+                dst = zero_table_for(rows, n_rows, d, g.device, f"g_leaky{i}")
+                N.call("lkg_scatter_add_rows_range_f32", ids.numel(), d, N.ptr(part), d, N.ptr(ids), 0, n_rows, N.ptr(dst),
+                       _ld(dst), _stream())
+                outs.append(dst)
+            return (outs[0], outs[1] if len(outs) > 1 else None, None)
         ga = tag_rows(_elt(3, g, saved[0], ctx.slope), rows) if ctx.needs_input_grad[0] else None
         gb = tag_rows(_elt(3, g, saved[1], ctx.slope), rows) if len(saved) > 1 and ctx.needs_input_grad[1] else None
         return ga, gb, None
