@@ -143,6 +143,41 @@ def c3_step_timing(h, t, r, n, d, dev):
     return out
 
 
+def default_arch_step_timing(h, t, r, n, dev):
+    """The reference's DEFAULT architecture (argument_pretraining.py:34-62) on the same graph: embed_dim = relation_dim =
+    scale_gat_dim = 300, eight gcn layers of conv_dim 32, GateMul (2 numeric + 300 text literals), TransR, dropout 0.1,
+    batch 2049 triples -- pre_training forward and forward + backward (median of 10 after 3 warm-ups)."""
+    from types import SimpleNamespace
+    import literalkg_amd as L
+    from literalkg_amd.synth import make_batch
+    cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=300, relation_dim=300, scale_gat_dim=300,
+                          use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=8,
+                          conv_dim=32, mess_dropout=0.1, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
+                          pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=300,
+                          use_num_lit=True, use_txt_lit=True, milestone_score=0.5, n_mlp_layers=2, mlp_hidden_dim=64)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    num = torch.rand(n, 2, generator=gen).to(dev)
+    txt = torch.randn(n, 300, generator=gen).to(dev)
+    model = L.LiteralKG(cfg, n, 16, None, num, txt).to(dev)
+    hd, td, rd = (torch.from_numpy(a).to(dev) for a in (h, t, r))
+    model(hd, td, rd, list(range(16)), device=dev, mode="update_att")
+    batch = [torch.from_numpy(a).to(dev) for a in make_batch(n, 683, 3)]
+    model.train()
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        model(*batch, device=dev, mode="pre_training").backward()
+    with torch.no_grad():
+        fwd = _timed(lambda: model(*batch, device=dev, mode="pre_training"))
+    step = _timed(fwd_bwd)
+    out = {"config": "the reference's default architecture: LiteralKG gcn x8 (conv_dim 32) over 300-wide embeddings + GateMul "
+                     "(2 + 300 literals) + linear_gat 556 -> 300, TransR 300 x 300, dropout 0.1, batch 2049 triples, same graph",
+           "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
+           "pre_training_step_edges_per_s": 8 * len(h) / step * 1e3}
+    del model
+    return out
+
+
 def whole_path_timings(h, t, r, n, d, dev):
     """Context numbers for the same graph (SURVEY.md 8d ii-iv), outside the headline metric: the drop-in
     module's update_att, one pre_training step (1 gcn layer, D=d, TransR, 2049 triples) forward /
@@ -239,6 +274,8 @@ def whole_path_timings(h, t, r, n, d, dev):
     del model, att, layer
     out["gate"] = gate_timing(n, d, dev)
     out["c3_step"] = c3_step_timing(h, t, r, n, d, dev)
+    torch.cuda.empty_cache()
+    out["default_architecture_step"] = default_arch_step_timing(h, t, r, n, dev)
     return out
 
 
