@@ -133,7 +133,9 @@ int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr, const int
  * neighbours in the autograd graph cost no pass of their own:
  *   add2               out[i,:] += add2[i,:]  -- in the backward, the gradient that reaches `ego` through its OTHER use
  *                      (the concatenated table keeps a copy of the layer input, model.py:300-309), which autograd
- *                      would otherwise add in a separate N x D pass;
+ *                      would otherwise add in a separate N x D pass; ld_add2 = 0 adds the SAME row to every output
+ *                      row: the bias of a gcn layer whose Linear was applied BEFORE the aggregation
+ *                      ((ego + A ego) W^T + b = p + A p + b with p = ego W^T, model.py:108-111, when out_dim < in_dim);
  *   add2_rows          (nullable, uint8[n_rows]) add2 is read for the rows whose byte is non-zero only: the loss's
  *                      gradient of the concatenated table touches <= 3B rows (lkg_fill_rows_f32 keeps the flags);
  *   copy_src/copy_dst  copy_dst[i,:] = copy_src[i,:] -- in the forward, that copy itself (the raw entity table into

@@ -576,7 +576,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     LKG_REQUIRE(rowptr && x && out, "lkg_spmm_csr_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
     LKG_REQUIRE(!self || ld_self >= d, "lkg_spmm_csr_f32: self stride %lld smaller than d=%d", (long long)ld_self, d);
-    LKG_REQUIRE(!add2 || ld_add2 >= d, "lkg_spmm_csr_fused_f32: add2 stride %lld smaller than d=%d", (long long)ld_add2, d);
+    LKG_REQUIRE(!add2 || ld_add2 >= d || ld_add2 == 0, "lkg_spmm_csr_fused_f32: add2 stride %lld smaller than d=%d (0 = one row for "
+                "every output row)", (long long)ld_add2, d);
     LKG_REQUIRE(!copy_dst || (copy_src && ld_copy_src >= d && ld_copy_dst >= d),
                 "lkg_spmm_csr_fused_f32: the row copy needs a source and strides >= d=%d", d);
     const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && lkg_aligned16(x) && lkg_aligned16(out) &&

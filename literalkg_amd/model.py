@@ -34,9 +34,9 @@ class AttentionCSR:
         self.val_t = val_t if val_t is not None else (
             ops.permute_values(val, graph.t_perm) if graph.t_perm is not None and val.is_cuda else None)
 
-    def aggregate(self, ego: torch.Tensor, plus_self: bool = False) -> torch.Tensor:
-        """A_in @ ego  (plus_self: ego + A_in @ ego in the same pass)."""
-        return ops.aggregate(ego, self.graph, self.val, self.val_t, plus_self)
+    def aggregate(self, ego: torch.Tensor, plus_self: bool = False, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A_in @ ego  (plus_self: ego + A_in @ ego in the same pass; bias: a row added to every output row)."""
+        return ops.aggregate(ego, self.graph, self.val, self.val_t, plus_self, bias)
 
 
 class _KeepingAttention:
@@ -139,6 +139,13 @@ class Aggregator(nn.Module):
         h0 = all_layers[0]
         kind = self.aggregator_type
         if kind == "gcn":   # ego + side comes out of the SpMM directly
+            att = getattr(A_in, "att", A_in)         # (layer 1 arrives wrapped: _KeepingAttention)
+            if not self.use_residual and 2 * self.out_dim <= self.in_dim and isinstance(att, AttentionCSR):
+                # a layer that narrows (the reference's default: 300 -> 32): (ego + A ego) W^T + b = p + A p + b with
+                # p = ego W^T -- the aggregation gathers out_dim columns per entry instead of in_dim, forward and backward.
+                # Same sums in another order (fp32 rounding only); the bias rides in the SpMM's epilogue.
+                p = ops.linear(ego, self.linear.weight, None)
+                return self._finish(att.aggregate(p, True, bias=self.linear.bias))
             z = self._lin(self.linear, self.residual_connection(A_in.aggregate(ego, True), h0, lamda, alpha, l))
             return self._finish(z)
         if kind == "gin":

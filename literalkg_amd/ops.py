@@ -122,14 +122,15 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
              copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None,
              x_rows: Optional[torch.Tensor] = None, self_rows: Optional[torch.Tensor] = None,
-             out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out_rows: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
     epilogue also copies src[i,:] to dst[i,:] (a row copy riding along instead of a pass of its own).  add2_rows /
     x_rows / self_rows (uint8 per row of add2 / x / add_self): the operand is zero outside the flagged rows and is read
     there only (x_rows is indexed like x: by col - x_row_offset).  out_rows (uint8 per output row, with x_rows): receives
-    1 where a row got a contribution; the other rows of ``out`` are NOT written (the caller keeps them zero)."""
+    1 where a row got a contribution; the other rows of ``out`` are NOT written (the caller keeps them zero).
+    bias (float32[d], instead of add2): the same row added to every output row."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -139,6 +140,9 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
         raise ValueError(f"spmm_raw: out must be a float32 {n_rows} x {d} tensor with unit column stride (got {tuple(out.shape)})")
     if rowptr.numel() < n_rows + 1 or col.numel() != val.numel():
         raise ValueError("spmm_raw: rowptr needs n_rows + 1 offsets, col and val one element per stored entry")
+    if bias is not None:
+        if add2 is not None or bias.numel() != d or bias.dtype != torch.float32 or not bias.is_contiguous():
+            raise ValueError(f"spmm_raw: bias must be a contiguous float32 vector of {d} elements and excludes add2")
     for name_, t_ in (("add_self", add_self), ("add2", add2)):
         if t_ is not None and tuple(t_.shape) != (n_rows, d):
             raise ValueError(f"spmm_raw: {name_} must be {n_rows} x {d} (got {tuple(t_.shape)})")
@@ -151,8 +155,8 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
         raise ValueError("spmm_raw: copy destination must be an n_rows x d view with unit column stride")
     N.call("lkg_spmm_csr_fused_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
            x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
-           _ld(add_self) if add_self is not None else 0, N.ptr(add2), _ld(add2) if add2 is not None else 0,
-           N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
+           _ld(add_self) if add_self is not None else 0, N.ptr(add2 if bias is None else bias),
+           _ld(add2) if add2 is not None else 0, N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
            N.ptr(rowmax), (x_rows.data_ptr() - x_row_offset) if x_rows is not None else None,
            N.ptr(self_rows if add_self is not None else None), N.ptr(out_rows), N.ptr(long_rows),
            0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
@@ -620,18 +624,30 @@ class _Aggregate(Function):
     model.py:261)."""
 
     @staticmethod
-    def forward(ctx, ego, g: KGStructure, val, val_t, plus_self):
-        _need_gpu(ego, val)
+    def forward(ctx, ego, g: KGStructure, val, val_t, plus_self, bias=None):
+        _need_gpu(ego, val, bias)
         _check_table(ego, g, val)
         ctx.g = g
         ctx.val_t = val_t
         ctx.plus_self = plus_self
+        ctx.has_bias = bias is not None
         rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
         return tag_rowmax(spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
-                                   add_self=ego if plus_self else None, rowmax=rm), rm)
+                                   add_self=ego if plus_self else None, rowmax=rm,
+                                   bias=bias.detach().contiguous() if bias is not None else None), rm)
 
     @staticmethod
     def backward(ctx, grad):
+        g_ego, *rest = _Aggregate._backward_ego(ctx, grad)
+        g_bias = None
+        if ctx.has_bias and ctx.needs_input_grad[5]:        # the bias reaches every row: its gradient is the column sum
+            rs = tagged_rows(grad)
+            g_bias = (colsum(gather_rows_range(grad, rs.compact_ids(), 0, grad.shape[0]))
+                      if rows_worth_compacting(rs, grad.shape[0]) else colsum(grad))
+        return (g_ego, *rest, g_bias)
+
+    @staticmethod
+    def _backward_ego(ctx, grad):
         g = ctx.g
         if g.t_rowptr is None:
             raise RuntimeError("KGStructure was built without its transpose; backward needs the CSC")
@@ -659,9 +675,9 @@ class _Aggregate(Function):
 
 
 def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor,
-              plus_self: bool = False) -> torch.Tensor:
-    """side = A @ ego, or ego + side in one pass when plus_self."""
-    return _Aggregate.apply(ego, g, val, val_t, plus_self)
+              plus_self: bool = False, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """side = A @ ego, or ego + side in one pass when plus_self; bias: a row added to every output row."""
+    return _Aggregate.apply(ego, g, val, val_t, plus_self, bias)
 
 
 class _AggregateKeep(Function):
