@@ -1075,11 +1075,21 @@ def test_module_matches_oracle_at_the_reference_default_architecture(L, O, gpu_d
     _module_against_oracle(L, O, gpu_device, "gcn", 8, 300, 32, "mul", 300, "transr")
 
 
-def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, scale, scoring):
+def test_module_matches_oracle_with_a_hundred_relations(L, O, gpu_device):
+    """total_rel = 100 (argument_pretraining.py:31): a hundred W_r matrices / relation rows through the grouped projection
+    and the attention refresh, on a narrowing two-layer model."""
+    _module_against_oracle(L, O, gpu_device, "gcn", 2, 128, 32, "num", 64, "transr", n_rel=100)
+
+
+def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, scale, scoring, n_rel=16):
     from literalkg_amd.synth import make_batch, make_kg
     from literalkg_amd import io
     n, e = 20_000, 150_000
     h, t, r = make_kg(n, e, seed=5)
+    if n_rel != 16:
+        r = np.random.default_rng(17).integers(0, n_rel, len(r))
+        _, first = np.unique(np.stack([h, r, t], 1), axis=0, return_index=True)
+        h, t, r = h[first], t[first], r[first]
     cfg = O.default_cfg(embed_dim=dim, relation_dim=dim if scoring == "transr" else (scale or dim + conv_dim * layers),
                         conv_dim=conv_dim, n_conv_layers=layers, aggregation_type=agg, scale_gat_dim=scale,
                         use_num_lit=gate in ("mul", "num"), use_txt_lit=gate in ("mul", "txt"),
@@ -1089,13 +1099,15 @@ def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, s
     num = torch.rand(n, 2) if cfg.use_num_lit else None
     txt = torch.randn(n, cfg.txt_lit_dim) if cfg.use_txt_lit else None
     a_in = io.initial_a_in(n, h, t, r)
-    m = L.LiteralKG(cfg, n, 16, a_in, num, txt, scoring=scoring)
+    m = L.LiteralKG(cfg, n, n_rel, a_in, num, txt, scoring=scoring)
     with torch.no_grad():                      # larger-than-xavier values so every term matters
         m.entity_embed.weight.mul_(30)
         m.relation_embed.weight.mul_(3)
     params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
     m.to(gpu_device).eval()
     batch = [torch.from_numpy(x) for x in make_batch(n, 200, 3, seed=9)]
+    if n_rel != 16:
+        batch[1] = torch.from_numpy(np.repeat(np.random.default_rng(23).integers(0, n_rel, 200), 3))
     loss = m(*[b.to(gpu_device) for b in batch], device=gpu_device, mode="pre_training")
     loss.backward()
     p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
@@ -1114,9 +1126,9 @@ def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, s
     hd, td, rd = (torch.from_numpy(x).to(gpu_device) for x in (h, t, r))
     if cfg.relation_dim != cfg.embed_dim:       # the reference cannot add the two embeddings either (model.py:441)
         with pytest.raises(ValueError, match="embed_dim must equal relation_dim"):
-            m(hd, td, rd, list(range(16)), device=gpu_device, mode="update_att")
+            m(hd, td, rd, list(range(n_rel)), device=gpu_device, mode="update_att")
         return
-    m(hd, td, rd, list(range(16)), device=gpu_device, mode="update_att")
+    m(hd, td, rd, list(range(n_rel)), device=gpu_device, mode="update_att")
     ref_a = O.attention_refresh(n, params["entity_embed.weight"], params["relation_embed.weight"],
                                 torch.from_numpy(h), torch.from_numpy(t), torch.from_numpy(r)).coalesce()
     got_a = m.A_in.data.cpu()
