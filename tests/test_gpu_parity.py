@@ -1081,6 +1081,14 @@ def test_module_matches_oracle_with_a_hundred_relations(L, O, gpu_device):
     _module_against_oracle(L, O, gpu_device, "gcn", 2, 128, 32, "num", 64, "transr", n_rel=100)
 
 
+@pytest.mark.parametrize("gate,scale", [(None, None), (None, 48), ("txt", None)])
+def test_narrowing_gcn_layers_project_before_they_aggregate(L, O, gpu_device, gate, scale):
+    """gcn layers whose Linear narrows (128 -> 32) run it BEFORE the aggregation ((ego + A ego) W^T + b = p + A p + b): without a
+    gate the first layer's input is the raw entity table (kept as slot 0 of the concatenated table by a copy or, for the
+    TransR loss, not at all), with one the gate's output."""
+    _module_against_oracle(L, O, gpu_device, "gcn", 2, 128, 32, gate, scale, "transr")
+
+
 def _module_against_oracle(L, O, gpu_device, agg, layers, dim, conv_dim, gate, scale, scoring, n_rel=16):
     from literalkg_amd.synth import make_batch, make_kg
     from literalkg_amd import io
