@@ -1024,7 +1024,11 @@ class _AssembleCat(Function):
             if p.data_ptr() != s.data_ptr() or p.stride() != s.stride():
                 s.copy_(p)                       # a part that was not produced in place (e.g. the raw entity table)
         ctx.offsets = holder.offsets
-        return holder.buf
+        # An ALIAS of the buffer, not the buffer itself: the parts are views of holder.buf, and a consumer below may have
+        # saved one for its backward (a Linear applied to slot 0, the gate's output).  With buf itself as this node's
+        # output, buf -> grad_fn -> ... -> saved view -> its base buf would be a cycle of C++ references that only a
+        # backward pass breaks: every forward WITHOUT one (an evaluation run with grad enabled) kept its whole graph.
+        return holder.buf.detach()
 
     @staticmethod
     def backward(ctx, g):

@@ -19,6 +19,7 @@ ap.add_argument("--prune", action="store_true")
 ap.add_argument("--fused-adam", action="store_true")
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--e", type=int, default=10_000_000)
+ap.add_argument("--groups", type=int, default=None, help="sampled heads per batch (default 683; the reference's pre_training_batch_size is 2048)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfgs = {
@@ -60,7 +61,7 @@ model(hd, td, rd, list(range(16)), device=dev, mode="update_att"); torch.cuda.sy
 print(f"first update_att incl. host CSR build: {(time.perf_counter()-t0)*1e3:.0f} ms")
 ua = sync_time(lambda: model(hd, td, rd, list(range(16)), device=dev, mode="update_att"))
 k_neg = cfg.pre_training_neg_rate
-bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, 683 if k_neg == 3 else 128, k_neg))
+bh, br, bp, bn = (torch.from_numpy(a).to(dev) for a in make_batch(n, args.groups or (683 if k_neg == 3 else 128), k_neg))
 if args.fused_adam:
     from literalkg_amd.optim import Adam
     opt = Adam(model.parameters(), lr=1e-4)
