@@ -1179,6 +1179,55 @@ def test_forward_without_backward_leaves_nothing_behind(L, O, gpu_device, agg, c
     assert before - torch.cuda.memory_allocated() >= 0
 
 
+def test_inference_heads_reuse_the_table_until_something_changes(L, O, gpu_device):
+    """evaluate() (utils/model_utils.py:40-75) calls mode='predict' once per batch of heads under eval() + no_grad; the
+    encoder's table is recomputed only when a parameter, A_in or a literal table changed since the last call."""
+    from literalkg_amd.synth import make_kg
+    from literalkg_amd import io
+    n, dim = 5000, 32
+    h, t, r = make_kg(n, 40_000, seed=4)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, use_num_lit=True, device=gpu_device)
+    torch.manual_seed(0)
+    num = torch.rand(n, 2)
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), num, None).to(gpu_device)
+    calls = []
+    real = m.gat_embeddings
+    m.gat_embeddings = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    heads = [torch.arange(i, i + 50, device=gpu_device) for i in (0, 50, 100)]
+    tails = torch.arange(200, 700, device=gpu_device)
+    m.eval()
+    with torch.no_grad():
+        s0 = [m(hh, tails, device=gpu_device, mode="predict") for hh in heads]
+        assert len(calls) == 1                                   # three batches of heads, ONE encoder pass
+        m.entity_embed.weight.mul_(1.5)                          # an in-place edit (an optimizer step is one)
+        s1 = m(heads[0], tails, device=gpu_device, mode="predict")
+        assert len(calls) == 2
+        hd, td, rd = (torch.from_numpy(x).to(gpu_device) for x in (h, t, r))
+        m(hd, td, rd, list(range(16)), device=gpu_device, mode="update_att")      # A_in replaced
+        m(heads[0], tails, device=gpu_device, mode="predict")
+        assert len(calls) == 3
+        m.numerical_literals_embed.add_(0.25)                    # a literal table edited in place
+        m(heads[0], tails, device=gpu_device, mode="predict")
+        m(heads[1], tails, device=gpu_device, mode="predict")
+        assert len(calls) == 4
+    m(heads[0], tails, device=gpu_device, mode="predict")        # grad enabled: never cached
+    m(heads[0], tails, device=gpu_device, mode="predict")
+    assert len(calls) == 6
+    m.train()
+    with torch.no_grad():
+        m(heads[0], tails, device=gpu_device, mode="predict")    # training mode (dropout): never cached
+        m(heads[0], tails, device=gpu_device, mode="predict")
+    assert len(calls) == 8
+    # and the cached answers are the uncached ones
+    m.eval()
+    del m.gat_embeddings
+    with torch.no_grad():
+        a = m(heads[2], tails, device=gpu_device, mode="predict")
+        m._eval_cache = None
+        b = m(heads[2], tails, device=gpu_device, mode="predict")
+    assert torch.equal(a, b) and s0[0].shape == (50, 500) and s1.shape == (50, 500)
+
+
 def test_module_moves_and_reloads_on_device(L, O, gpu_device):
     gd = load_golden("encoder_gcn_l2_scale")
     m = _build_model(L, gd, torch.device("cpu"), "transr")            # built and loaded on the CPU
