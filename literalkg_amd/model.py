@@ -530,8 +530,7 @@ class LiteralKG(nn.Module):
             raise AttributeError("call initialize_MLP() first (model.py:499)")
         head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
         self.gat_embed, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
-        eh = pruned.gather_rows(self.gat_embed, head_ids)
-        et = pruned.gather_rows(self.gat_embed, tail_ids)
+        eh, et = ops.gather_rows_pair(self.gat_embed, head_ids, tail_ids, self._table_grad_stays_inside())
         c = eh.shape[1]
         w1 = self.fc1.weight
         x = ops.multi_linear((eh, et), (w1[:, :c], w1[:, c:]), self.fc1.bias)       # fc1 over [e_h | e_t], no cat

@@ -1428,6 +1428,44 @@ def dot_loss(emb, h, pos_t, neg_t, lam, sparse_rows: bool = False):
     return _DotLoss.apply(emb, h, pos_t, neg_t, lam, sparse_rows)
 
 
+class _GatherPair(Function):
+    """(table[ids_a], table[ids_b]) for the pair head (model.py:506-512) with ONE backward: both row gradients scattered
+    into one table -- the shared all-zero table of _RowScratch when the caller says the gradient stays inside the package,
+    tagged with the rows it touches, so that everything below runs on those rows (two separate index ops would hand
+    autograd two dense N x C tables to add, and the sum carries no row set)."""
+
+    @staticmethod
+    def forward(ctx, table, ids_a, ids_b, sparse_rows):
+        _need_gpu(table, ids_a, ids_b)
+        ids_a, ids_b = _i64(ids_a), _i64(ids_b)
+        ctx.save_for_backward(ids_a, ids_b)
+        ctx.meta = (tuple(table.shape), table.device, bool(sparse_rows))
+        ctx.set_materialize_grads(False)
+        return gather_rows(table, ids_a), gather_rows(table, ids_b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ids_a, ids_b = ctx.saved_tensors
+        shape, device, sparse = ctx.meta
+        if sparse and _HAS_USE_COUNT:
+            ent = _RowScratch.acquire(shape[0], shape[1], device)
+            ent.mark(ids_a, ids_b)
+            g_tab = ent.table(RowSet(ent.flags, [ids_a, ids_b]))
+        else:
+            g_tab = torch.zeros(shape, dtype=torch.float32, device=device)
+        for g, ids in ((ga, ids_a), (gb, ids_b)):
+            if g is None:
+                continue
+            g = _f32_rows(g)
+            N.call("lkg_scatter_add_rows_f32", ids.numel(), shape[1], N.ptr(g), _ld(g), N.ptr(ids), None, N.ptr(g_tab),
+                   _ld(g_tab), _stream())
+        return g_tab, None, None, None
+
+
+def gather_rows_pair(table: torch.Tensor, ids_a: torch.Tensor, ids_b: torch.Tensor, sparse_rows: bool = False):
+    return _GatherPair.apply(table, ids_a, ids_b, sparse_rows)
+
+
 # ----------------------------------------------------------------------------- f1 MLP head
 class _ReluBatchNorm(Function):
     """y = BatchNorm1d(relu(z)) (model.py:515-516); updates the running buffers in training mode."""

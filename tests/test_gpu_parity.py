@@ -1850,7 +1850,7 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
 
 
 @pytest.mark.parametrize("variant", ["dropout_train", "gin", "scale_gat_dim", "gatemul_3layers", "transe", "fine_tuning",
-                                     "sage_res_dropout", "gatenum_scale_dropout"])
+                                     "sage_res_dropout", "gatenum_scale_dropout", "mlp_head"])
 def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, variant):
     """The row-sparse backward (kept-zero tables, row sets, gradient frontier, Linear backward on listed rows) is active
     from 16 384 entity rows on -- sizes the reference-fixture tests do not reach.  Here every model family runs at 40 k
@@ -1880,14 +1880,20 @@ def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, varia
         over.update(aggregation_type="graphsage", use_residual=True, mess_dropout=0.2); train = True
     elif variant == "gatenum_scale_dropout":
         over.update(use_num_lit=True, scale_gat_dim=80, mess_dropout=0.1); train = True
+    elif variant == "mlp_head":
+        over.update(scale_gat_dim=48); mode = "mlp"
     cfg = O.default_cfg(**over)
     torch.manual_seed(5)
     num = torch.rand(n, 2) if cfg.use_num_lit else None
     txt = torch.randn(n, cfg.txt_lit_dim) if cfg.use_txt_lit else None
     m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), num, txt, scoring=scoring).to(gpu_device)
+    if mode == "mlp":
+        torch.manual_seed(6)
+        m.initialize_MLP()
     m.train(train)
     bh, br, bp, bn = (torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 60, 3, seed=3))
-    args = (bh, br, bp, bn) if mode == "pre_training" else (bh, bp, bn)
+    args = (bh, br, bp, bn) if mode == "pre_training" else ((bh, bp) if mode == "mlp" else (bh, bp, bn))
+    weights = torch.linspace(-1.0, 1.0, bh.numel(), device=gpu_device).reshape(-1, 1)
     ops._RowScratch._tables.clear()
 
     def grads(sparse):
@@ -1897,6 +1903,8 @@ def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, varia
         for step in range(2):                       # two steps: the second re-uses the kept-zero tables of the first
             torch.manual_seed(100 + step)           # the dropout seeds follow torch's CPU generator
             loss = m(*args, device=gpu_device, mode=mode)
+            if mode == "mlp":                       # (B x 1 sigmoid outputs: a weighted sum stands in for the driver's BCE)
+                loss = (loss * weights).sum()
             loss.backward()
             out.append(float(loss.detach()))
         return out, {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
