@@ -102,6 +102,7 @@ class Aggregator(nn.Module):
                 self.out_linear = nn.Linear(hid, out_dim)
                 self.mlp_layer_norms = nn.ModuleList(nn.LayerNorm(hid) for _ in range(self.num_layers - 1))
         self.last_normalized = None
+        self.h0_projection = None   # set by the encoder for the duration of a pass: linear_h0(h0) of this layer
         self.norm_out = None   # set by the encoder: the concat-buffer slice the normalised copy goes to
         self.want_output = True   # ... and False for the last layer: nobody reads its un-normalised output
 
@@ -109,7 +110,10 @@ class Aggregator(nn.Module):
     def residual_connection(self, hi, h0, lamda, alpha, l):
         if not self.use_residual:
             return hi
-        h0p = ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
+        # linear_h0(h0): handed in by the encoder (all layers' projections of the same h0 as ONE product, and one copy for
+        # both branches of bi-interaction) or computed here
+        h0p = self.h0_projection if self.h0_projection is not None else \
+            ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
         mixed = ops.axpby(hi, h0p, 1 - alpha, alpha)
         beta = math.log(lamda / l + 1)
         return ops.matmul(mixed, ops.axpby(self.weight, None, beta, 1 - beta))
@@ -317,6 +321,12 @@ class LiteralKG(nn.Module):
         defer = (defer_slot0 and cur is self.entity_embed.weight and self.scale_gat_dim is None
                  and isinstance(att, AttentionCSR))
         kept = [cur]
+        res_layers = [layer for layer in self.aggregator_layers if layer.use_residual]
+        if len(res_layers) > 1 and cur.is_cuda:      # every layer projects the SAME h0 (model.py:93): one stacked product
+            projections = ops.stacked_linear(cur, [layer.linear_h0.weight for layer in res_layers],
+                                             [layer.linear_h0.bias for layer in res_layers])
+            for layer, proj in zip(res_layers, projections):
+                layer.h0_projection = proj        # (cleared layer by layer below; all of them if a layer raises)
         for idx, layer in enumerate(self.aggregator_layers):
             layer.norm_out = cb.slot(idx + 1)
             layer.want_output = idx + 1 < len(self.aggregator_layers)     # (the last layer's y is read by nobody)
@@ -326,9 +336,14 @@ class LiteralKG(nn.Module):
                    if (idx == 0 and isinstance(att, AttentionCSR)) else att)
             try:
                 cur = layer(cur, a_k, kept, self.lamda, self.alpha, idx + 1)
+            except BaseException:
+                for other in self.aggregator_layers:
+                    other.h0_projection = None
+                raise
             finally:
                 layer.norm_out = None
                 layer.want_output = True
+                layer.h0_projection = None
             if a_k is not att and a_k.kept is not None:
                 kept[0] = a_k.kept
             kept.append(layer.last_normalized)   # F.normalize of the (dropped-out) layer output, fused

@@ -798,6 +798,72 @@ def multi_linear(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], b=None)
     return _MultiLinear.apply(b, len(xs), *xs, *ws)
 
 
+class _StackedLinear(Function):
+    """ys[l] = x @ ws[l]^T + bs[l] for several Linears over the SAME input, as ONE product (the GCNII-style residual projects
+    the layer-0 table h0 once per layer, model.py:93: eight Linears over the same N x embed_dim input at the reference's
+    main.py defaults -- and bi-interaction asks for each of them twice).  Forward: one GEMM over the stacked weights, the
+    outputs are its column slices.  Backward: the slices' gradients side by side in one buffer, ONE data-gradient product
+    (K = the stacked width) instead of one N x embed_dim table per Linear for autograd to add up, one weight-gradient
+    product, one column sum."""
+
+    @staticmethod
+    def forward(ctx, x, n_lin, *wb):
+        ws, bs = wb[:n_lin], wb[n_lin:]
+        _need_gpu(x, *ws, *bs)
+        x = _f32_rows(x)
+        w_all = torch.cat([w.detach() for w in ws], 0).contiguous()
+        b_all = torch.cat([b.detach() for b in bs]).contiguous()
+        m, k = x.shape
+        n = w_all.shape[0]
+        if tall_ok(m, n, (k,), single_panel_too=True):
+            y = gemm_tall((x,), ((w_all,),), True, b_all)
+        else:
+            y = gemm(x, w_all, trans_b=True, bias=b_all)
+        ctx.save_for_backward(x, w_all)
+        ctx.widths = [int(w.shape[0]) for w in ws]
+        ctx.set_materialize_grads(False)
+        outs, o = [], 0
+        for wd in ctx.widths:
+            outs.append(y[:, o:o + wd])
+            o += wd
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, w_all = ctx.saved_tensors
+        m, n = x.shape[0], w_all.shape[0]
+        g_all = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        o = 0
+        for wd, g in zip(ctx.widths, gs):
+            if g is None:
+                g_all[:, o:o + wd].zero_()
+            else:
+                fill_slot(g_all, o, g)
+            o += wd
+        n_lin = len(ctx.widths)
+        need = ctx.needs_input_grad
+        gx = gemm(g_all, w_all) if need[0] else None
+        gws, gbs = [None] * n_lin, [None] * n_lin
+        if any(need[2:2 + n_lin]):
+            gw_all = gemm(g_all, x, trans_a=True)
+            o = 0
+            for i, wd in enumerate(ctx.widths):
+                gws[i] = gw_all[o:o + wd] if need[2 + i] else None
+                o += wd
+        if any(need[2 + n_lin:]):
+            gb_all = colsum(g_all)
+            o = 0
+            for i, wd in enumerate(ctx.widths):
+                gbs[i] = gb_all[o:o + wd] if need[2 + n_lin + i] else None
+                o += wd
+        return (gx, None, *gws, *gbs)
+
+
+def stacked_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]):
+    """[x @ w^T + b for w, b in zip(ws, bs)] as one product, forward and backward."""
+    return _StackedLinear.apply(x, len(ws), *ws, *bs)
+
+
 class _MatMul(Function):
     @staticmethod
     def forward(ctx, a, b):

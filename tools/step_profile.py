@@ -23,6 +23,10 @@ ap.add_argument("--groups", type=int, default=None, help="sampled heads per batc
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfgs = {
+    # main.py's defaults (argument.py:34-118): bi-interaction WITH the GCNII-style residual, eight layers of 32 over 300-wide
+    # embeddings, GateMul, linear_gat 556 -> 256
+    "main_default": dict(embed_dim=300, relation_dim=300, conv_dim=32, n_conv_layers=8, use_num_lit=True, use_txt_lit=True,
+                         scale_gat_dim=256, mess_dropout=0.1, aggregation_type="bi-interaction", use_residual=True),
     # the reference's DEFAULT architecture (argument_pretraining.py:34-62): 300-wide embeddings, eight gcn layers of 32, GateMul,
     # linear_gat 556 -> 300, TransR 300 x 300 per relation
     "default": dict(embed_dim=300, relation_dim=300, conv_dim=32, n_conv_layers=8, use_num_lit=True, use_txt_lit=True,
