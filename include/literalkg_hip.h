@@ -428,6 +428,14 @@ int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t 
 int lkg_gemm_smallm_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
 int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
                         float *c, int64_t ldc, void *stream);
+/* Skinny products over many rows: C[m, n] = A[m, k] . op(B) (+ bias) (+ beta C) for k, n <= 64 (op(B) = B[k, n], or
+ * B[n, k]^T with trans_b: an nn.Linear weight) -- the 32 x 32 Linears, data gradients and residual mixes of narrow aggregation
+ * layers (model.py:93-130 at the reference's default conv_dim 32).  Exact f32 FMAs on the VALU at streaming rate: op(B) stays
+ * in LDS, 64 rows of A per turn, one row x n / 4 columns per thread.  lkg_gemm_skinny_ok: m >= 4096, k and n <= 64 in
+ * multiples of 4, rows of A and C 16-byte aligned.                                                                  */
+int lkg_gemm_skinny_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *c, int64_t ldc);
+int lkg_gemm_skinny_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                        int32_t trans_b, float beta, float *c, int64_t ldc, const float *bias, void *stream);
 /* out[c] = max_r |x[r,c]|  (out is overwritten)                                                     */
 int lkg_col_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, void *stream);
 

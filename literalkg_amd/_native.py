@@ -71,6 +71,8 @@ PROTOTYPES = {
     "lkg_gemm_longk_ok": [i64, i64, i64, vp, i64, vp, i64],
     "lkg_gemm_longk_f32": [i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_smallm_ok": [i64, i64, i64, vp, i64, vp, i64],
+    "lkg_gemm_skinny_ok": [i64, i64, i64, vp, i64, vp, i64],
+    "lkg_gemm_skinny_f32": [i64, i64, i64, vp, i64, vp, i64, i32, f32, vp, i64, vp, vp],
     "lkg_gemm_smallm_f32": [i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_wgrad_f32": [i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp],
     "lkg_colsum_weighted_f32": [i64, i32, vp, i64, vp, i64, i32, vp, vp, i64, vp],

@@ -851,3 +851,97 @@ extern "C" int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float 
     LKG_CHECK_LAUNCH("lkg_gemm_smallm_f32");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny products over many rows: C[m, n] = A[m, k] . op(B) (+ bias) (+ beta C) with k, n <= 64 -- the 32 x 32 Linears, their
+// data gradients and the residual mix of narrow aggregation layers (the reference's defaults stack eight layers of 32:
+// argument.py:56-58).  1 M x 32 x 32 moves 256 MB and 2 GFLOP: the matrix-core engines spend a 128-column tile (and
+// an operand split, or a row-scale pass) on it, 0.22 ms; here it is exact f32 on the VALU at the rate the rows stream:
+// a persistent workgroup keeps op(B) in LDS, stages 64 rows of A per turn, every thread owns one row x n / 4 columns.
+namespace {
+
+template <int CPT>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(long m, int n, int k, const float *__restrict__ a, long lda,
+                                                           const float *__restrict__ b, long ldb, int trans_b, float beta,
+                                                           float *__restrict__ c, long ldc, const float *__restrict__ bias) {
+    constexpr int KP = 68;                              // LDS row pitch of the A tile (k <= 64, +4: conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) float ws[64][4 * CPT], xs[64][KP];
+    const int t = threadIdx.x;
+    const int r = t >> 2, cg = t & 3;                   // this thread: row r of the tile, columns cg * CPT .. + CPT
+    // op(B)[kk][col] into LDS once (zero-padded to 4 * CPT columns)
+    for (int i = t; i < k * 4 * CPT; i += 256) {
+        const int kk = i / (4 * CPT), col = i % (4 * CPT);
+        ws[kk][col] = col < n ? (trans_b ? b[(long)col * ldb + kk] : b[(long)kk * ldb + col]) : 0.f;
+    }
+    float bv[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) bv[j] = (bias && cg * CPT + j < n) ? bias[cg * CPT + j] : 0.f;
+    const int k4 = k >> 2;
+    for (long m0 = (long)blockIdx.x * 64; m0 < m; m0 += (long)gridDim.x * 64) {
+        __syncthreads();                                // (the previous tile's readers are done; B is in place on the first turn)
+        for (int p = t; p < 64 * k4; p += 256) {        // 16-byte pieces of the 64 x k tile
+            const int rr = p / k4, q = p % k4;
+            const long row = min(m0 + rr, m - 1);
+            *reinterpret_cast<float4 *>(&xs[rr][4 * q]) = *reinterpret_cast<const float4 *>(a + row * lda + 4 * q);
+        }
+        __syncthreads();
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = bv[j];
+        for (int q = 0; q < k4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4 *>(&xs[r][4 * q]);
+            const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < CPT; j += 4) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(&ws[4 * q + e][cg * CPT + j]);
+                    acc[j] = fmaf(xe[e], wv.x, acc[j]);
+                    acc[j + 1] = fmaf(xe[e], wv.y, acc[j + 1]);
+                    acc[j + 2] = fmaf(xe[e], wv.z, acc[j + 2]);
+                    acc[j + 3] = fmaf(xe[e], wv.w, acc[j + 3]);
+                }
+        }
+        const long row = m0 + r;
+        if (row < m) {
+            float *dst = c + row * ldc + cg * CPT;
+#pragma unroll
+            for (int j = 0; j < CPT; j += 4) {
+                if (cg * CPT + j >= n) break;           // (n is a multiple of 4: a group of four is in or out)
+                float4 o = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+                if (beta != 0.f) {
+                    const float4 old = *reinterpret_cast<const float4 *>(dst + j);
+                    o.x = fmaf(beta, old.x, o.x); o.y = fmaf(beta, old.y, o.y); o.z = fmaf(beta, old.z, o.z); o.w = fmaf(beta, old.w, o.w);
+                }
+                *reinterpret_cast<float4 *>(dst + j) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 1 when lkg_gemm_skinny_f32 takes this product: many rows, k and n <= 64 in multiples of 4, 16-byte aligned rows of A and C
+extern "C" int lkg_gemm_skinny_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *c, int64_t ldc) {
+    return m >= 4096 && k >= 4 && k <= 64 && n >= 4 && n <= 64 && k % 4 == 0 && n % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
+           lkg_aligned16(a) && lkg_aligned16(c);
+}
+
+extern "C" int lkg_gemm_skinny_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
+                                   int32_t trans_b, float beta, float *c, int64_t ldc, const float *bias, void *stream) {
+    LKG_REQUIRE(m > 0 && a && b && c && lda >= k && ldc >= n && ldb >= (trans_b ? k : n), "lkg_gemm_skinny_f32: bad arguments");
+    LKG_REQUIRE(lkg_gemm_skinny_ok(m, n, k, a, lda, c, ldc), "lkg_gemm_skinny_f32: needs m >= 4096, k and n <= 64 in multiples "
+                "of 4 and 16-byte aligned rows (lkg_gemm_skinny_ok)");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)std::min<int64_t>((m + 63) / 64, 256 * 8);
+#define LKG_SKINNY(CPT_)                                                                                                    \
+    hipLaunchKernelGGL((skinny_gemm_kernel<CPT_>), dim3(blocks), dim3(256), 0, s, (long)m, (int)n, (int)k, a, (long)lda, b,  \
+                       (long)ldb, (int)trans_b, beta, c, (long)ldc, bias)
+    if (n <= 16) LKG_SKINNY(4);
+    else if (n <= 32) LKG_SKINNY(8);
+    else if (n <= 48) LKG_SKINNY(12);
+    else LKG_SKINNY(16);
+#undef LKG_SKINNY
+    LKG_CHECK_LAUNCH("lkg_gemm_skinny_f32");
+    return LKG_OK;
+}

@@ -179,6 +179,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         raise ValueError(f"gemm: out must be a float32 {m} x {n} tensor with unit column stride (got {tuple(out.shape)})")
     if bias is not None and bias.numel() != n:
         raise ValueError(f"gemm: bias of {bias.numel()} elements for {n} output columns")
+    if (not trans_a and alpha == 1.0 and _ENGINE != "f32"
+            and N.load().lkg_gemm_skinny_ok(m, n, k, N.ptr(a), _ld(a), N.ptr(out), _ld(out))):
+        # narrow in AND out (the 32 x 32 products of narrow layers): exact f32 on the VALU at streaming rate
+        N.call("lkg_gemm_skinny_f32", m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), int(trans_b), float(beta), N.ptr(out),
+               _ld(out), N.ptr(bias), _stream())
+        return out
     if not trans_a and k > 0 and tall_ok(m, n, (k,), single_panel_too=tagged_rowmax(a) is not None):
         return gemm_tall((a,), ((b,),), bool(trans_b), bias, alpha, beta, out)
     if (trans_a and not trans_b and alpha == 1.0 and beta == 0.0 and bias is None and _WGRAD_ENGINE == "longk"
@@ -731,8 +737,10 @@ class _MultiLinear(Function):
         xs, ws = xw[:n_terms], xw[n_terms:]
         _need_gpu(*xs, *ws)
         y = None
-        if tall_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs],
-                   single_panel_too=tagged_rowmax(xs[0]) is not None):
+        if n_terms == 1 and _skinny(xs[0], ws[0].shape[0]):
+            y = gemm(xs[0], ws[0], trans_b=True, bias=bias)            # (narrow in and out: the streaming VALU kernel)
+        elif tall_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs],
+                     single_panel_too=tagged_rowmax(xs[0]) is not None):
             # every panel in ONE launch: the accumulators stay in registers, the inputs are read once
             y = gemm_tall(xs, (ws,), True, bias)
         else:
@@ -757,6 +765,8 @@ class _MultiLinear(Function):
         for i in range(n):
             if not ctx.needs_input_grad[2 + i]:
                 gxs.append(None)
+            elif _skinny(gy, ws[i].shape[1]):
+                gxs.append(gemm(gy, ws[i]))
             elif tall_ok(gy.shape[0], ws[i].shape[1], (gy.shape[1],), single_panel_too=tagged_rowmax(gy) is not None):
                 rm = rows_absmax((gy,)) if rm is None else rm    # one scale (tagged by the producer, or one pass) for all
                 gxs.append(gemm_tall((gy,), ((ws[i],),), False, rowmax=rm))
@@ -788,6 +798,12 @@ class _MultiLinear(Function):
             gws.append(gemm(gc, gather_rows_range(xs[i], ids, 0, n_rows), trans_a=True)
                        if ctx.needs_input_grad[2 + n + i] else None)
         return (gb, None, *gxs, *gws)
+
+
+def _skinny(x: torch.Tensor, n_out: int) -> bool:
+    """Is x @ W^T (n_out columns) a product for lkg_gemm_skinny_f32 (many rows, <= 64 columns in and out)?"""
+    return (x.dim() == 2 and x.shape[0] >= 4096 and 4 <= x.shape[1] <= 64 and 4 <= n_out <= 64 and x.shape[1] % 4 == 0
+            and n_out % 4 == 0 and _ENGINE != "f32" and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
 def linear(x, w, b=None):

@@ -1758,6 +1758,35 @@ def test_last_layer_backward_on_the_listed_rows_equals_the_dense_backward(ops, g
     assert float(res[1][0][flags == 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,n,k,tb", [(50_000, 32, 32, 1), (50_000, 32, 32, 0), (9_001, 64, 16, 1), (4_096, 20, 44, 0),
+                                      (30_000, 48, 64, 1), (12_345, 8, 60, 0)])
+def test_skinny_products_on_the_valu(ops, gpu_device, m, n, k, tb):
+    """lkg_gemm_skinny_f32 (A[m, k] . op(B) for k, n <= 64 over many rows: the Linears / data gradients / residual mixes of
+    32-wide layers) through ops.gemm, against f64: plain, with bias, accumulating (beta = 1), on column slices of wider
+    tables."""
+    from literalkg_amd import _native as N
+    torch.manual_seed(m + n)
+    wide = torch.randn(m, k + 8, device=gpu_device)
+    b = torch.randn((n, k) if tb else (k, n), device=gpu_device)
+    bias = torch.randn(n, device=gpu_device)
+    for a in (wide[:, :k].contiguous(), wide[:, 4:4 + k]):
+        out_wide = torch.randn(m, n + 12, device=gpu_device)
+        out = out_wide[:, 8:8 + n]
+        assert N.load().lkg_gemm_skinny_ok(m, n, k, N.ptr(a), ops._ld(a), N.ptr(out), ops._ld(out))
+        old = out.clone()
+        want = a.double() @ (b.double().t() if tb else b.double())
+        got = ops.gemm(a, b, trans_b=bool(tb))
+        scale = (a.double().abs() @ (b.double().abs().t() if tb else b.double().abs())) + 1e-300
+        ref32 = (a @ (b.t() if tb else b)).double()                                       # hipBLASLt f32
+        e_f32 = float(((ref32 - want).abs() / scale).max())
+        assert float(((got.double() - want).abs() / scale).max()) <= max(2 * e_f32, 5e-7)
+        got_b = ops.gemm(a, b, trans_b=bool(tb), bias=bias)
+        assert float(((got_b.double() - want - bias.double()).abs() / (scale + bias.abs().double())).max()) <= max(2 * e_f32, 5e-7)
+        ops.gemm(a, b, trans_b=bool(tb), beta=1.0, out=out)
+        assert float(((out.double() - want - old.double()).abs() / (scale + old.abs().double())).max()) <= max(2 * e_f32, 5e-7)
+        assert torch.equal(out_wide[:, :8], out_wide[:, :8]) and float(out_wide[:, 8 + n:].abs().max()) > 0
+
+
 @pytest.mark.parametrize("m,n,k", [(32, 32, 100_000), (32, 300, 50_001), (64, 64, 20_000), (16, 8, 4096), (48, 132, 9_999),
                                    (64, 556, 30_000)])
 def test_narrow_weight_gradient_on_the_valu(ops, gpu_device, m, n, k):
