@@ -448,6 +448,19 @@ int lkg_colsum_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out
 int lkg_colsum_weighted_f32(int64_t n, int32_t d, const float *x, int64_t ldx, const float *w, int64_t ldw,
                             int32_t n_w, float *out_sum, float *out_w, int64_t ld_out_w, void *stream);
 
+/* bi-interaction's element-wise front (model.py:123-128) fused with the GCNII-style residual's mix (model.py:94):
+ *   out_sum = c (ego + side) + alpha h0p,  out_prod = c (ego * side) + alpha h0p,  c = 1 - alpha
+ * (h0p NULL: c = 1 and no h0p term: the plain sum and product) in one pass over ego / side / h0p, and its backward
+ *   g_ego = c (g_sum + g_prod * side),  g_side = c (g_sum + g_prod * ego),  g_h0p = alpha (g_sum + g_prod)
+ * in one pass (g_ego, g_side, g_h0p: dense n x d outputs; g_h0p only with has_h0).  Replaces four element-wise ops of
+ * the reference per layer (and eight-plus autograd kernels behind them).                                       */
+int lkg_bi_mix_fwd_f32(int64_t n, int32_t d, const float *ego, int64_t lde, const float *side, int64_t lds,
+                       const float *h0p, int64_t ldh, float alpha, float *out_sum, int64_t ldos, float *out_prod,
+                       int64_t ldop, void *stream);
+int lkg_bi_mix_bwd_f32(int64_t n, int32_t d, const float *ego, int64_t lde, const float *side, int64_t lds,
+                       const float *g_sum, int64_t ldgs, const float *g_prod, int64_t ldgp, int32_t has_h0, float alpha,
+                       float *g_ego, float *g_side, float *g_h0p, void *stream);
+
 /* Small element-wise steps of the layers (row-major n x d, row strides in elements):
  *   op 0  out = alpha * a + beta * b   (b NULL: alpha * a + beta)   GCNII residual mix, model.py:94-96; 'gin' sums
  *   op 1  out = a * b                                                ego * side of 'bi-interaction', model.py:127

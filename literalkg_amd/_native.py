@@ -77,6 +77,8 @@ PROTOTYPES = {
     "lkg_gemm_wgrad_f32": [i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp],
     "lkg_colsum_weighted_f32": [i64, i32, vp, i64, vp, i64, i32, vp, vp, i64, vp],
     "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],
+    "lkg_bi_mix_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, i64, vp],
+    "lkg_bi_mix_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, i32, f32, vp, vp, vp, vp],
     "lkg_adam_step_f32": [i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp],
 }
 _RESTYPE = {"lkg_last_error": C.c_char_p, "lkg_csr_build_device_workspace": C.c_int64,

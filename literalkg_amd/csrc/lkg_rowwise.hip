@@ -1255,3 +1255,136 @@ extern "C" int lkg_eltwise_f32(int32_t op, int64_t n, int32_t d, const float *a,
     LKG_CHECK_LAUNCH("lkg_eltwise_f32");
     return LKG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bi-interaction's element-wise front (model.py:123-128, with the residual's mix of model.py:94): from ego, side (and the
+// layer's projection h0p of the layer-0 table when the GCNII-style residual is on)
+//     out_sum  = c (ego + side) + alpha h0p          out_prod = c (ego * side) + alpha h0p        c = 1 - alpha (1, 0 without h0p)
+// in ONE pass (the reference's four: sum, product and two mixes), and its backward in one:
+//     g_ego = c (g_sum + g_prod * side)     g_side = c (g_sum + g_prod * ego)     g_h0p = alpha (g_sum + g_prod)
+// -- main.py's defaults (argument.py:52-58, 108) run this in each of eight 32-wide layers every step.
+namespace {
+template <int W>
+__global__ __launch_bounds__(256) void bi_mix_fwd_kernel(long n, int d, int log_tpr, const float *__restrict__ ego, long lde,
+                                                          const float *__restrict__ side, long lds,
+                                                          const float *__restrict__ h0p, long ldh, float alpha,
+                                                          float *__restrict__ out_sum, long ldos,
+                                                          float *__restrict__ out_prod, long ldop) {
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c0 = (threadIdx.x & (tpr - 1)) * W;
+    const float c = h0p ? 1.f - alpha : 1.f;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+        for (int col = c0; col < d; col += tpr * W) {
+            float e[W], s[W], h[W], os[W], op[W];
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(e) = *reinterpret_cast<const float4 *>(ego + r * lde + col);
+                *reinterpret_cast<float4 *>(s) = *reinterpret_cast<const float4 *>(side + r * lds + col);
+                if (h0p) *reinterpret_cast<float4 *>(h) = *reinterpret_cast<const float4 *>(h0p + r * ldh + col);
+            } else {
+                e[0] = ego[r * lde + col];
+                s[0] = side[r * lds + col];
+                if (h0p) h[0] = h0p[r * ldh + col];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float hh = h0p ? alpha * h[k] : 0.f;
+                os[k] = fmaf(c, e[k] + s[k], hh);
+                op[k] = fmaf(c, e[k] * s[k], hh);
+            }
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(out_sum + r * ldos + col) = *reinterpret_cast<float4 *>(os);
+                *reinterpret_cast<float4 *>(out_prod + r * ldop + col) = *reinterpret_cast<float4 *>(op);
+            } else {
+                out_sum[r * ldos + col] = os[0];
+                out_prod[r * ldop + col] = op[0];
+            }
+        }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void bi_mix_bwd_kernel(long n, int d, int log_tpr, const float *__restrict__ ego, long lde,
+                                                          const float *__restrict__ side, long lds,
+                                                          const float *__restrict__ g_sum, long ldgs,
+                                                          const float *__restrict__ g_prod, long ldgp, int has_h0, float alpha,
+                                                          float *__restrict__ g_ego, float *__restrict__ g_side,
+                                                          float *__restrict__ g_h0p) {
+    const int tpr = 1 << log_tpr, rpb = 256 >> log_tpr;
+    const int c0 = (threadIdx.x & (tpr - 1)) * W;
+    const float c = has_h0 ? 1.f - alpha : 1.f;
+    for (long r = (long)blockIdx.x * rpb + (threadIdx.x >> log_tpr); r < n; r += (long)gridDim.x * rpb)
+        for (int col = c0; col < d; col += tpr * W) {
+            float e[W], s[W], gs[W], gp[W], ge[W], gsd[W], gh[W];
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(e) = *reinterpret_cast<const float4 *>(ego + r * lde + col);
+                *reinterpret_cast<float4 *>(s) = *reinterpret_cast<const float4 *>(side + r * lds + col);
+                *reinterpret_cast<float4 *>(gs) = *reinterpret_cast<const float4 *>(g_sum + r * ldgs + col);
+                *reinterpret_cast<float4 *>(gp) = *reinterpret_cast<const float4 *>(g_prod + r * ldgp + col);
+            } else {
+                e[0] = ego[r * lde + col];
+                s[0] = side[r * lds + col];
+                gs[0] = g_sum[r * ldgs + col];
+                gp[0] = g_prod[r * ldgp + col];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                ge[k] = c * fmaf(gp[k], s[k], gs[k]);
+                gsd[k] = c * fmaf(gp[k], e[k], gs[k]);
+                gh[k] = alpha * (gs[k] + gp[k]);
+            }
+            const long o = r * (long)d + col;          // (the three gradients are dense n x d tensors of this call)
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4 *>(g_ego + o) = *reinterpret_cast<float4 *>(ge);
+                *reinterpret_cast<float4 *>(g_side + o) = *reinterpret_cast<float4 *>(gsd);
+                if (g_h0p) *reinterpret_cast<float4 *>(g_h0p + o) = *reinterpret_cast<float4 *>(gh);
+            } else {
+                g_ego[o] = ge[0];
+                g_side[o] = gsd[0];
+                if (g_h0p) g_h0p[o] = gh[0];
+            }
+        }
+}
+}  // namespace
+
+extern "C" int lkg_bi_mix_fwd_f32(int64_t n, int32_t d, const float *ego, int64_t lde, const float *side, int64_t lds,
+                                  const float *h0p, int64_t ldh, float alpha, float *out_sum, int64_t ldos, float *out_prod,
+                                  int64_t ldop, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && lde >= d && lds >= d && ldos >= d && ldop >= d && (!h0p || ldh >= d), "lkg_bi_mix_fwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(ego && side && out_sum && out_prod, "lkg_bi_mix_fwd_f32: null pointer");
+    const bool vec = d % 4 == 0 && lde % 4 == 0 && lds % 4 == 0 && ldos % 4 == 0 && ldop % 4 == 0 && (!h0p || ldh % 4 == 0) &&
+                     lkg_aligned16(ego) && lkg_aligned16(side) && lkg_aligned16(out_sum) && lkg_aligned16(out_prod) &&
+                     (!h0p || lkg_aligned16(h0p));
+    const int lt = log_threads_per_row(vec ? d / 4 : d);
+    const int64_t blocks = std::min<int64_t>((n + (256 >> lt) - 1) / (256 >> lt), 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(bi_mix_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, lt, ego,
+                           (long)lde, side, (long)lds, h0p, (long)ldh, alpha, out_sum, (long)ldos, out_prod, (long)ldop);
+    else
+        hipLaunchKernelGGL(bi_mix_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, lt, ego,
+                           (long)lde, side, (long)lds, h0p, (long)ldh, alpha, out_sum, (long)ldos, out_prod, (long)ldop);
+    LKG_CHECK_LAUNCH("lkg_bi_mix_fwd_f32");
+    return LKG_OK;
+}
+
+extern "C" int lkg_bi_mix_bwd_f32(int64_t n, int32_t d, const float *ego, int64_t lde, const float *side, int64_t lds,
+                                  const float *g_sum, int64_t ldgs, const float *g_prod, int64_t ldgp, int32_t has_h0,
+                                  float alpha, float *g_ego, float *g_side, float *g_h0p, void *stream) {
+    LKG_REQUIRE(n >= 0 && d > 0 && lde >= d && lds >= d && ldgs >= d && ldgp >= d, "lkg_bi_mix_bwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;
+    LKG_REQUIRE(ego && side && g_sum && g_prod && g_ego && g_side && (!has_h0 || g_h0p), "lkg_bi_mix_bwd_f32: null pointer");
+    const bool vec = d % 4 == 0 && lde % 4 == 0 && lds % 4 == 0 && ldgs % 4 == 0 && ldgp % 4 == 0 && lkg_aligned16(ego) &&
+                     lkg_aligned16(side) && lkg_aligned16(g_sum) && lkg_aligned16(g_prod) && lkg_aligned16(g_ego) &&
+                     lkg_aligned16(g_side) && (!g_h0p || lkg_aligned16(g_h0p));
+    const int lt = log_threads_per_row(vec ? d / 4 : d);
+    const int64_t blocks = std::min<int64_t>((n + (256 >> lt) - 1) / (256 >> lt), 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(bi_mix_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, lt, ego,
+                           (long)lde, side, (long)lds, g_sum, (long)ldgs, g_prod, (long)ldgp, (int)has_h0, alpha, g_ego, g_side,
+                           has_h0 ? g_h0p : nullptr);
+    else
+        hipLaunchKernelGGL(bi_mix_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, d, lt, ego,
+                           (long)lde, side, (long)lds, g_sum, (long)ldgs, g_prod, (long)ldgp, (int)has_h0, alpha, g_ego, g_side,
+                           has_h0 ? g_h0p : nullptr);
+    LKG_CHECK_LAUNCH("lkg_bi_mix_bwd_f32");
+    return LKG_OK;
+}

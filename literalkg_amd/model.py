@@ -165,6 +165,20 @@ class Aggregator(nn.Module):
                 z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
             return self._finish(z)
         if kind == "bi-interaction":
+            if ego.is_cuda:
+                # sum, product and (with the residual) both mixes (1 - a) hi + a linear_h0(h0) in ONE kernel, one for their
+                # backward; the identity-mapping matrix (1 - b) + b W once for both branches
+                h0p = None
+                if self.use_residual:
+                    h0p = self.h0_projection if self.h0_projection is not None else \
+                        ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
+                ms, mp = ops.bi_mix(ego, side, h0p, alpha)
+                if self.use_residual:
+                    beta = math.log(lamda / l + 1)
+                    wp = ops.axpby(self.weight, None, beta, 1 - beta)
+                    ms, mp = ops.matmul(ms, wp), ops.matmul(mp, wp)
+                s, b = self._lin(self.linear1, ms), self._lin(self.linear2, mp)
+                return self._finish(ops.leaky_relu_sum(b, s), slope=1.0)
             s = self._lin(self.linear1, self.residual_connection(ops.axpby(ego, side), h0, lamda, alpha, l))
             b = self._lin(self.linear2, self.residual_connection(ops.mul(ego, side), h0, lamda, alpha, l))
             # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): one kernel, then a slope-1

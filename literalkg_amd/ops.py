@@ -953,6 +953,50 @@ def mul(a, b):
     return _Mul.apply(a, b)
 
 
+class _BiMix(Function):
+    """(c (ego + side) + alpha h0p, c (ego * side) + alpha h0p) with c = 1 - alpha, or the plain (sum, product) without h0p:
+    bi-interaction's two branch inputs (model.py:123-128) and the residual's mix (model.py:94) in ONE pass, one pass back."""
+
+    @staticmethod
+    def forward(ctx, ego, side, h0p, alpha):
+        _need_gpu(ego, side, h0p)
+        ego, side = _f32_rows(ego), _f32_rows(side)
+        h = _f32_rows(h0p) if h0p is not None else None
+        if side.shape != ego.shape or (h is not None and h.shape != ego.shape):
+            raise ValueError("bi_mix: ego, side (and h0p) must have one shape")
+        n, d = ego.shape
+        out_sum = torch.empty((n, d), dtype=torch.float32, device=ego.device)
+        out_prod = torch.empty((n, d), dtype=torch.float32, device=ego.device)
+        N.call("lkg_bi_mix_fwd_f32", n, d, N.ptr(ego), _ld(ego), N.ptr(side), _ld(side), N.ptr(h), _ld(h) if h is not None else 0,
+               float(alpha), N.ptr(out_sum), d, N.ptr(out_prod), d, _stream())
+        ctx.save_for_backward(ego, side)
+        ctx.cfg = (h is not None, float(alpha))
+        ctx.set_materialize_grads(False)
+        return out_sum, out_prod
+
+    @staticmethod
+    def backward(ctx, g_sum, g_prod):
+        ego, side = ctx.saved_tensors
+        has_h0, alpha = ctx.cfg
+        if g_sum is None and g_prod is None:
+            return None, None, None, None
+        rs, rp = tagged_rows(g_sum), tagged_rows(g_prod)
+        rows = rs if (rs is rp or g_prod is None) else (rp if g_sum is None else None)     # (one row set: it travels on)
+        g_sum = _f32_rows(g_sum) if g_sum is not None else torch.zeros_like(ego)
+        g_prod = _f32_rows(g_prod) if g_prod is not None else torch.zeros_like(ego)
+        n, d = ego.shape
+        g_ego = torch.empty((n, d), dtype=torch.float32, device=ego.device)
+        g_side = torch.empty((n, d), dtype=torch.float32, device=ego.device)
+        g_h = torch.empty((n, d), dtype=torch.float32, device=ego.device) if has_h0 else None
+        N.call("lkg_bi_mix_bwd_f32", n, d, N.ptr(ego), _ld(ego), N.ptr(side), _ld(side), N.ptr(g_sum), _ld(g_sum), N.ptr(g_prod),
+               _ld(g_prod), int(has_h0), float(alpha), N.ptr(g_ego), N.ptr(g_side), N.ptr(g_h), _stream())
+        return tag_rows(g_ego, rows), tag_rows(g_side, rows), (tag_rows(g_h, rows) if has_h0 else None), None
+
+
+def bi_mix(ego, side, h0p=None, alpha: float = 0.0):
+    return _BiMix.apply(ego, side, h0p, alpha)
+
+
 class _LeakySum(Function):
     """leaky_relu(a) + leaky_relu(b)  (b None: leaky_relu(a))."""
 
