@@ -122,6 +122,28 @@ class Aggregator(nn.Module):
     def _lin(mod: nn.Linear, x):
         return ops.linear(x, mod.weight, mod.bias)
 
+    def _identity_map(self, lamda, l):
+        """(1 - b) + b W, b = ln(lamda / l + 1): the GCNII-style identity mapping (model.py:95-96)."""
+        beta = math.log(lamda / l + 1)
+        return ops.axpby(self.weight, None, beta, 1 - beta)
+
+    def _lin_mapped(self, mod: nn.Linear, mixed, wp):
+        """mod(mixed @ wp) as ONE product over the rows: mixed @ (wp @ W^T) + b -- the two weight matrices are multiplied
+        first (d x d x out: nothing), the N-row product runs once, at the Linear's output width (for the 300-wide first layer
+        of main.py's defaults: 1 M x 300 x 32 instead of 1 M x 300 x 300 and then 1 M x 300 x 32, forward and backward).
+        Same value up to fp32 rounding order."""
+        return ops.linear(mixed, ops.matmul(mod.weight, wp.t()), mod.bias)
+
+    def _res_lin(self, mod: nn.Linear, hi, h0, lamda, alpha, l):
+        """mod(residual_connection(hi)), with the identity mapping folded into the Linear's weight on the device path."""
+        if not self.use_residual:
+            return self._lin(mod, hi)
+        if not hi.is_cuda:
+            return self._lin(mod, self.residual_connection(hi, h0, lamda, alpha, l))
+        h0p = self.h0_projection if self.h0_projection is not None else \
+            ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
+        return self._lin_mapped(mod, ops.axpby(hi, h0p, 1 - alpha, alpha), self._identity_map(lamda, l))
+
     def _finish(self, z, extra_sum=None, slope=ops.LEAKY_SLOPE):
         """LeakyReLU -> LayerNorm -> message dropout, plus the L2-normalised copy of the result that
         gat_embeddings concatenates (model.py:161, 305) -- one fused kernel."""
@@ -150,7 +172,7 @@ class Aggregator(nn.Module):
                 # Same sums in another order (fp32 rounding only); the bias rides in the SpMM's epilogue.
                 p = ops.linear(ego, self.linear.weight, None)
                 return self._finish(att.aggregate(p, True, bias=self.linear.bias))
-            z = self._lin(self.linear, self.residual_connection(A_in.aggregate(ego, True), h0, lamda, alpha, l))
+            z = self._res_lin(self.linear, A_in.aggregate(ego, True), h0, lamda, alpha, l)
             return self._finish(z)
         if kind == "gin":
             return self._gin(ego, A_in.aggregate(ego, True), h0, all_layers, lamda, alpha, l)
@@ -159,7 +181,7 @@ class Aggregator(nn.Module):
             if self.use_residual:
                 wh = self.linear_h.weight
                 hi = ops.multi_linear((ego, side), (wh[:, :self.in_dim], wh[:, self.in_dim:]), self.linear_h.bias)
-                z = self._lin(self.linear, self.residual_connection(hi, h0, lamda, alpha, l))
+                z = self._res_lin(self.linear, hi, h0, lamda, alpha, l)
             else:   # Linear over [ego | side] as two accumulating GEMMs, no cat
                 w = self.linear.weight
                 z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
@@ -174,10 +196,10 @@ class Aggregator(nn.Module):
                         ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
                 ms, mp = ops.bi_mix(ego, side, h0p, alpha)
                 if self.use_residual:
-                    beta = math.log(lamda / l + 1)
-                    wp = ops.axpby(self.weight, None, beta, 1 - beta)
-                    ms, mp = ops.matmul(ms, wp), ops.matmul(mp, wp)
-                s, b = self._lin(self.linear1, ms), self._lin(self.linear2, mp)
+                    wp = self._identity_map(lamda, l)
+                    s, b = self._lin_mapped(self.linear1, ms, wp), self._lin_mapped(self.linear2, mp, wp)
+                else:
+                    s, b = self._lin(self.linear1, ms), self._lin(self.linear2, mp)
                 return self._finish(ops.leaky_relu_sum(b, s), slope=1.0)
             s = self._lin(self.linear1, self.residual_connection(ops.axpby(ego, side), h0, lamda, alpha, l))
             b = self._lin(self.linear2, self.residual_connection(ops.mul(ego, side), h0, lamda, alpha, l))
@@ -196,8 +218,7 @@ class Aggregator(nn.Module):
         for lin, norm in zip(self.linears, self.mlp_layer_norms):
             h, _ = ops.act_layernorm(self._lin(lin, h), norm.weight, norm.bias, want_norm=False)
             stack = ops.axpby(stack, h)
-        x = self.residual_connection(stack, h0, lamda, alpha, l)
-        z = self._lin(self.out_linear, x)
+        z = self._res_lin(self.out_linear, stack, h0, lamda, alpha, l)
         if len(all_layers) > 1:
             return self._finish(z, extra_sum=list(all_layers[1:]))
         return self._finish(z)
