@@ -143,15 +143,17 @@ def c3_step_timing(h, t, r, n, d, dev):
     return out
 
 
-def default_arch_step_timing(h, t, r, n, dev):
-    """The reference's DEFAULT architecture (argument_pretraining.py:34-62) on the same graph: embed_dim = relation_dim =
-    scale_gat_dim = 300, eight gcn layers of conv_dim 32, GateMul (2 numeric + 300 text literals), TransR, dropout 0.1,
-    batch 2049 triples -- pre_training forward and forward + backward (median of 10 after 3 warm-ups)."""
+def default_arch_step_timing(h, t, r, n, dev, main_py=False):
+    """The reference's DEFAULT architectures on the same graph -- pre_training forward and forward + backward (median of 10
+    after 3 warm-ups), batch 2049 triples, dropout 0.1, GateMul (2 numeric + 300 text literals), TransR 300 x 300:
+    main_pretraining.py (argument_pretraining.py:34-62): embed_dim = relation_dim = scale_gat_dim = 300, eight gcn layers of 32;
+    main.py (argument.py:34-118, main_py=True): bi-interaction with the GCNII-style residual, scale_gat_dim = 256."""
     from types import SimpleNamespace
     import literalkg_amd as L
     from literalkg_amd.synth import make_batch
-    cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=300, relation_dim=300, scale_gat_dim=300,
-                          use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=8,
+    cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=300, relation_dim=300, scale_gat_dim=256 if main_py else 300,
+                          use_residual=bool(main_py), alpha=0.1, lamda=0.5,
+                          aggregation_type="bi-interaction" if main_py else "gcn", n_conv_layers=8,
                           conv_dim=32, mess_dropout=0.1, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
                           pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2, txt_lit_dim=300,
                           use_num_lit=True, use_txt_lit=True, milestone_score=0.5, n_mlp_layers=2, mlp_hidden_dim=64)
@@ -170,8 +172,10 @@ def default_arch_step_timing(h, t, r, n, dev):
     with torch.no_grad():
         fwd = _timed(lambda: model(*batch, device=dev, mode="pre_training"))
     step = _timed(fwd_bwd)
-    out = {"config": "the reference's default architecture: LiteralKG gcn x8 (conv_dim 32) over 300-wide embeddings + GateMul "
-                     "(2 + 300 literals) + linear_gat 556 -> 300, TransR 300 x 300, dropout 0.1, batch 2049 triples, same graph",
+    what = ("main.py's defaults: bi-interaction + GCNII-style residual x8 (conv_dim 32), linear_gat 556 -> 256" if main_py else
+            "main_pretraining.py's defaults: gcn x8 (conv_dim 32), linear_gat 556 -> 300")
+    out = {"config": f"the reference's default architecture ({what}) over 300-wide embeddings + GateMul (2 + 300 literals), "
+                     "TransR 300 x 300, dropout 0.1, batch 2049 triples, same graph",
            "pre_training_forward_ms": fwd, "pre_training_forward_backward_ms": step,
            "pre_training_step_edges_per_s": 8 * len(h) / step * 1e3}
     del model
@@ -276,6 +280,8 @@ def whole_path_timings(h, t, r, n, d, dev):
     out["c3_step"] = c3_step_timing(h, t, r, n, d, dev)
     torch.cuda.empty_cache()
     out["default_architecture_step"] = default_arch_step_timing(h, t, r, n, dev)
+    torch.cuda.empty_cache()
+    out["main_py_default_architecture_step"] = default_arch_step_timing(h, t, r, n, dev, main_py=True)
     return out
 
 
