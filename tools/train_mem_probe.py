@@ -13,7 +13,7 @@ from literalkg_amd.synth import make_kg, make_batch
 dev = torch.device("cuda:0")
 n, e = 200_000, 2_000_000
 h, t, r = make_kg(n, e)
-cfg = SimpleNamespace(use_pretrain=0, device=dev, use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", mess_dropout=0.1,
+cfg = SimpleNamespace(use_pretrain=0, device=dev, use_residual=bool(int(os.environ.get("RES", "0"))), alpha=0.1, lamda=0.5, aggregation_type=os.environ.get("AGG", "gcn"), mess_dropout=0.1,
             kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5, pre_training_neg_rate=3, fine_tuning_neg_rate=3, num_lit_dim=2,
             txt_lit_dim=300, milestone_score=0.5, n_mlp_layers=2, mlp_hidden_dim=64, embed_dim=300, relation_dim=300, scale_gat_dim=300,
             n_conv_layers=8, conv_dim=32, use_num_lit=True, use_txt_lit=True)
