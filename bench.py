@@ -431,7 +431,8 @@ class Watchdog:
     """N > 1 only.  The robust measurements come first; every optional phase after them (the pipelined exchange, which
     had never run over RCCL on the development boxes; the rows scheme; the integrated step) runs under a deadline.  If a
     phase hangs -- a collective that never completes cannot be caught as an exception -- rank 0 prints the JSON line of
-    what HAS been measured, naming the phase, and every rank leaves with exit code 0 instead of losing the run."""
+    what HAS been measured, naming the phase, and every rank leaves with exit code 3: a hang is a defect of the run, and the
+    run's records must say so (the partial line is there to find its cause from, not to pass as a result)."""
 
     def __init__(self, rank, emit):
         self.rank, self.emit, self.timer, self.phase = rank, emit, None, None
@@ -452,12 +453,16 @@ class Watchdog:
     def _fire(self):
         try:
             if self.rank == 0:
-                out = self.emit(f"phase '{self.phase}' did not finish within its deadline and was abandoned")
+                msg = f"HUNG: phase '{self.phase}' did not finish within its deadline; run abandoned with exit code 3"
+                sys.stderr.write("bench.py: " + msg + "\n")
+                sys.stderr.flush()
+                out = self.emit(msg)
                 if out is not None:
+                    out["hung_phase"] = self.phase
                     sys.stdout.write(json.dumps(out) + "\n")
                     sys.stdout.flush()
         finally:
-            os._exit(0)
+            os._exit(3)
 
 
 def main():

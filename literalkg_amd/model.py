@@ -452,6 +452,12 @@ class LiteralKG(nn.Module):
         self._eval_cache = (self._eval_key(), table)      # (keyed AFTER the pass: it may have moved the literals to the device)
         return table
 
+    def train(self, mode: bool = True):
+        """nn.Module.train; entering training mode drops the table the inference heads keep (N x C floats)."""
+        if mode:
+            self._eval_cache = None
+        return super().train(mode)
+
     def _embeddings_and_ids(self, *id_lists):
         """(table, relabelled ids): the full table with the ids as given, or the pruned table with positions."""
         if not self._can_prune():
@@ -469,12 +475,13 @@ class LiteralKG(nn.Module):
         # generate_kg_batch repeats every sampled (h, r, t+) pre_training_neg_rate times (dataloader.py:318-330): such
         # a batch projects h and t+ once per group.  Checked on the ids (any other batch takes the general path).
         h, pos_t, neg_t = ops.checked_ids(self.n_entities, h, pos_t, neg_t)     # (out-of-range ids never reach a kernel)
-        if self.scoring == "transe":       # (the TransR form checks r while it groups the batch by relation)
-            (r,) = ops.checked_ids(self.n_relations, r, what="relation")
+        (r,) = ops.checked_ids(self.n_relations, r, what="relation")
         check, k = None, int(self.pre_training_neg_rate)
         if self.scoring == "transr" and self.group_reuse and k >= self.group_reuse_min_rate:
             check = ops.GroupedCheck(h, r, pos_t, k)      # queued now, answered just before the loss (no idle device)
         keep = self.last_scores if not self.training else None
+        if self.training or torch.is_grad_enabled():
+            self._eval_cache = None           # a training step is under way: the inference heads' kept table goes
         if self.scoring == "transr" and not self._can_prune():
             # the loss reads <= 3B rows: the N-row copy of the raw entity table into slot 0 of the concatenated table is
             # deferred (made only if somebody asks for self.gat_embed), its columns are read from the raw table
@@ -482,9 +489,11 @@ class LiteralKG(nn.Module):
             table, raw = self.gat_embeddings(defer_slot0=True)
             self._gat_state = (table, raw)        # (a tuple: nn.Module would register a bare Parameter attribute)
             group = k if (check is not None and check.result()) else 1
+            self._raise_bad_ids()
             return ops.transr_loss(table, self.relation_embed.weight, self.gat_trans_M, h, r, pos_t, neg_t,
                                    self.kg_l2loss_lambda, keep, group, self._table_grad_stays_inside(), slot0=raw)
         self.gat_embed, (h, pos_t, neg_t) = self._embeddings_and_ids(h, pos_t, neg_t)
+        self._raise_bad_ids()
         sparse = self._table_grad_stays_inside()
         if self.scoring == "transr":
             group = k if (check is not None and check.result()) else 1
@@ -492,6 +501,14 @@ class LiteralKG(nn.Module):
                                    self.kg_l2loss_lambda, keep, group, sparse)
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
                                self.kg_l2loss_lambda, keep, sparse)
+
+    @staticmethod
+    def _raise_bad_ids():
+        """The ids a caller handed in were sanitised on the device at the start of the call (ops.checked_ids).  By now the
+        encoder's launches are queued BEHIND that kernel, so waiting for its event costs the device nothing -- and an id
+        outside its table raises IndexError inside the call, before a loss or a score exists and before anything is updated
+        (the reference's lookups raise at model.py:366-384 / 475-476)."""
+        ops.check_deferred_errors()
 
     @property
     def gat_embed(self):
@@ -555,6 +572,7 @@ class LiteralKG(nn.Module):
     def calc_score(self, head_ids, tail_ids):
         head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
         emb, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
+        self._raise_bad_ids()
         return ops.gemm(ops.gather_rows(emb.detach(), head_ids), ops.gather_rows(emb.detach(), tail_ids),
                         trans_b=True)
 
@@ -580,6 +598,7 @@ class LiteralKG(nn.Module):
             raise AttributeError("call initialize_MLP() first (model.py:499)")
         head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
         self.gat_embed, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
+        self._raise_bad_ids()
         eh, et = ops.gather_rows_pair(self.gat_embed, head_ids, tail_ids, self._table_grad_stays_inside())
         c = eh.shape[1]
         w1 = self.fc1.weight
@@ -593,6 +612,8 @@ class LiteralKG(nn.Module):
 
     def forward(self, *input, device, mode):
         self.device = device
+        if mode in ("pre_training", "fine_tuning", "mlp") and (self.training or torch.is_grad_enabled()):
+            self._eval_cache = None           # a training step: whatever table the inference heads kept is about to be stale
         if mode == "pre_training":
             return self.calc_triplet_loss(*input)
         if mode == "update_att":
@@ -610,5 +631,6 @@ class LiteralKG(nn.Module):
         head_ids, tail_pos_ids, tail_neg_ids = ops.checked_ids(self.n_entities, head_ids, tail_pos_ids, tail_neg_ids)
         self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
             head_ids, tail_pos_ids, tail_neg_ids)
+        self._raise_bad_ids()
         return ops.dot_loss(self.gat_embed, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda,
                             self._table_grad_stays_inside())

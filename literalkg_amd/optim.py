@@ -42,4 +42,8 @@ class Adam(torch.optim.Optimizer):
                 N.call("lkg_adam_step_f32", p.numel(), N.ptr(p), N.ptr(g), N.ptr(st["exp_avg"]),
                        N.ptr(st["exp_avg_sq"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                        float(group["weight_decay"]), int(st["step"]), ops._stream())
+                # the kernel wrote p through its raw pointer: tell autograd's version counter, as torch.optim.Adam's in-place
+                # ops do -- everything keyed on a parameter's version (the inference heads' kept table, a tensor saved for a
+                # backward) sees the step
+                torch.autograd.graph.increment_version(p)
         return loss

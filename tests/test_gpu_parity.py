@@ -1228,6 +1228,87 @@ def test_inference_heads_reuse_the_table_until_something_changes(L, O, gpu_devic
     assert torch.equal(a, b) and s0[0].shape == (50, 500) and s1.shape == (50, 500)
 
 
+def test_inference_table_is_dropped_by_training_steps_with_the_fused_adam(L, O, gpu_device):
+    """predict -> 3 pre_training steps with literalkg_amd.optim.Adam (which writes the parameters through raw pointers), NO
+    update_att in between -> predict: the second answer is an uncached recompute on the trained weights, not the table
+    kept from the first call (round 2 returned the pre-training scores here)."""
+    from literalkg_amd.optim import Adam
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, dim = 5000, 32
+    h, t, r = make_kg(n, 40_000, seed=4)
+    for form in ("transr", "transe"):
+        cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=1 if form == "transr" else 2,
+                            scale_gat_dim=None if form == "transr" else dim, device=gpu_device)
+        torch.manual_seed(0)
+        m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), scoring=form).to(gpu_device)
+        heads, tails = torch.arange(0, 50, device=gpu_device), torch.arange(200, 700, device=gpu_device)
+        m.eval()
+        with torch.no_grad():
+            s0 = m.calc_score(heads, tails).clone()
+        assert m.__dict__.get("_eval_cache") is not None
+        opt = Adam(m.parameters(), lr=1e-2)
+        batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 100, 3, seed=1)]
+        versions = [p._version for p in m.parameters() if p.requires_grad]
+        m.train()
+        assert m.__dict__.get("_eval_cache") is None              # entering training mode lets the N x C table go
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            m(*batch, device=gpu_device, mode="pre_training").backward()
+            opt.step()
+        after = [p._version for p in m.parameters() if p.requires_grad]
+        assert all(b_ > a_ for a_, b_, p in zip(versions, after, [p for p in m.parameters() if p.requires_grad])
+                   if p.grad is not None)                          # the raw-pointer update shows in the version counter
+        m.eval()
+        with torch.no_grad():
+            s1 = m.calc_score(heads, tails).clone()
+            m._eval_cache = None
+            s2 = m.calc_score(heads, tails)
+        assert torch.equal(s1, s2)
+        assert float((s1 - s0).abs().max()) > 1e-4
+        # ... and WITHOUT leaving eval mode (a driver that trains under eval(), dropout off): the cache key alone must see it
+        with torch.no_grad():
+            m.calc_score(heads, tails)
+        assert m.__dict__.get("_eval_cache") is not None
+        opt.zero_grad(set_to_none=True)
+        m(*batch, device=gpu_device, mode="pre_training").backward()
+        kept = m.__dict__.get("_eval_cache")
+        opt.step()
+        with torch.no_grad():
+            s3 = m.calc_score(heads, tails).clone()
+            m._eval_cache = None
+            s4 = m.calc_score(heads, tails)
+        assert torch.equal(s3, s4) and float((s3 - s1).abs().max()) > 1e-5
+        if kept is not None:                                       # (had the table survived the step, its key must not match)
+            assert kept[0] != m._eval_key()
+
+
+def test_out_of_range_ids_raise_inside_the_call(L, O, gpu_device):
+    """The reference's embedding lookups raise before anything is updated (model.py:366-384); here the ids are sanitised on
+    the device and the count is read behind the encoder's launches -- still inside the SAME call, before a loss exists."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io, ops
+    n, dim = 3000, 32
+    h, t, r = make_kg(n, 20_000, seed=4)
+    for form, rate in (("transr", 3), ("transr", 1), ("transe", 3)):
+        cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=1, pre_training_neg_rate=rate,
+                            scale_gat_dim=None if form == "transr" else dim, device=gpu_device)
+        m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), scoring=form).to(gpu_device).train()
+        bh, br, bp, bn = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 60, 3, seed=1)]
+        bad = bn.clone()
+        bad[7] = n + 5
+        with pytest.raises(IndexError):
+            m(bh, br, bp, bad, device=gpu_device, mode="pre_training")
+        ops.check_deferred_errors()                                # nothing left pending: the error was raised where it belongs
+        float(m(bh, br, bp, bn, device=gpu_device, mode="pre_training"))
+        with pytest.raises(IndexError):
+            m(bh, bp, bad, device=gpu_device, mode="fine_tuning")
+        m.eval()
+        with torch.no_grad(), pytest.raises(IndexError):
+            m(bad[:20], bp[:10], device=gpu_device, mode="predict")
+        ops.check_deferred_errors()
+
+
 def test_module_moves_and_reloads_on_device(L, O, gpu_device):
     gd = load_golden("encoder_gcn_l2_scale")
     m = _build_model(L, gd, torch.device("cpu"), "transr")            # built and loaded on the CPU
