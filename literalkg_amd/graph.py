@@ -30,6 +30,24 @@ LONG_ROW_THRESHOLD = 256   # rows above this get a whole workgroup in the SpMM (
 _ARRAYS = ("rowptr", "col", "eptr", "rel", "rel_first", "dup_entries", "dup_rows", "t_rowptr", "t_col", "t_perm")
 
 
+class StructurePart:
+    """A subset of the entries of a CSR (or of the CSC) as a CSR of its own over the same rows
+    (KGStructure.structure_parts): ``perm`` = id of each entry in the structure's CSR value array."""
+
+    def __init__(self, rowptr, col, perm, n_rows):
+        self.rowptr, self.col, self.perm, self.n = rowptr, col, perm, int(n_rows)
+        self.nnz = int(col.numel())
+        self._long = {}
+
+    def long_rows(self, lo: int = 0, hi: Optional[int] = None):
+        """Rows of [lo, hi) (relative to lo) with more than LONG_ROW_THRESHOLD entries, or None."""
+        hi = self.n if hi is None else hi
+        if (lo, hi) not in self._long:
+            rows = torch.nonzero((self.rowptr[lo + 1:hi + 1] - self.rowptr[lo:hi]) > LONG_ROW_THRESHOLD, as_tuple=True)[0].int()
+            self._long[(lo, hi)] = rows if rows.numel() else None
+        return self._long[(lo, hi)]
+
+
 class KGStructure:
     def __init__(self):
         self.n = 0
@@ -174,6 +192,36 @@ class KGStructure:
             rows = torch.nonzero((rp[lo + 1:hi + 1] - rp[lo:hi]) > LONG_ROW_THRESHOLD, as_tuple=True)[0].int()
             self._long[key] = rows if rows.numel() else None
         return self._long[key]
+
+    def structure_parts(self, transposed: bool, cuts, part_of_block) -> list:
+        """The CSR (or, transposed, the CSC) cut by the SOURCE of every entry -- the row it gathers from: its tail in the
+        CSR, its head in the CSC -- into sub-structures: an entry goes to part ``part_of_block[b]`` where b is the block
+        [cuts[b], cuts[b+1]) that holds its source.  Every part is a CSR of its own over all N rows (``StructurePart``:
+        entries of a row in their original order, ``perm`` = CSR entry id for the values), so that  A x = sum_p A_p x  can
+        run part by part, each part as soon as the rows of x it gathers from have arrived
+        (sharding.FeatureShardedAggregation).  Built once per structure with torch index ops on the structure's device
+        (index bookkeeping, like the frontier lists)."""
+        if transposed and self.t_rowptr is None:
+            raise RuntimeError("KGStructure was built without its transpose")
+        rowptr, col = (self.t_rowptr, self.t_col) if transposed else (self.rowptr, self.col)
+        dev = col.device
+        cuts = torch.as_tensor([int(c) for c in cuts], dtype=torch.int64, device=dev)
+        lookup = torch.as_tensor([int(x) for x in part_of_block], dtype=torch.int64, device=dev)
+        if cuts.numel() != lookup.numel() + 1 or int(cuts[0]) != 0 or int(cuts[-1]) != self.n:
+            raise ValueError("structure_parts: cuts must run from 0 to n with one part id per block")
+        n_parts = int(lookup.max()) + 1 if lookup.numel() else 0
+        part = lookup[torch.bucketize(col, cuts[1:-1].to(col.dtype), right=True)]
+        counts = (rowptr[1:] - rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(self.n, device=dev, dtype=torch.int32), counts)
+        parts = []
+        for p in range(n_parts):
+            idx = torch.nonzero(part == p, as_tuple=True)[0]
+            rp = torch.zeros(self.n + 1, dtype=torch.int64, device=dev)
+            if idx.numel():
+                rp[1:] = torch.cumsum(torch.bincount(row[idx].long(), minlength=self.n), 0)
+            perm = self.t_perm[idx].contiguous() if transposed else idx.int()
+            parts.append(StructurePart(rp.int(), col[idx].contiguous(), perm, self.n))
+        return parts
 
     # ------------------------------------------------------------------ views
     @property

@@ -610,8 +610,13 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
 
 
 def permute_values(val: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
-    out = torch.empty_like(val)
-    N.call("lkg_permute_f32", val.numel(), N.ptr(perm), N.ptr(val), N.ptr(out), _stream())
+    """out[i] = val[perm[i]] for an int32 index list of any length (the CSC's values, a part of them); the caller
+    guarantees 0 <= perm[i] < val.numel() -- the lists come from the structure build."""
+    _need_gpu(val, perm)
+    if perm.dtype != torch.int32 or val.dtype != torch.float32 or not perm.is_contiguous() or not val.is_contiguous():
+        raise TypeError("permute_values: contiguous float32 values and a contiguous int32 index list")
+    out = torch.empty(perm.numel(), dtype=val.dtype, device=val.device)
+    N.call("lkg_permute_f32", perm.numel(), N.ptr(perm), N.ptr(val), N.ptr(out), _stream())
     return out
 
 

@@ -85,12 +85,37 @@ def shard_bounds(graph: KGStructure, world: int) -> List[int]:
     return [int(c) for c in graph.row_cuts(world)]
 
 
+class _Whole:
+    """The whole CSR / CSC behind the interface of a StructurePart."""
+
+    def __init__(self, graph: KGStructure, transposed: bool):
+        self.rowptr, self.col = (graph.t_rowptr, graph.t_col) if transposed else (graph.rowptr, graph.col)
+        self.n, self.nnz = graph.n, graph.nnz
+        self._graph, self._t = graph, transposed
+
+    def long_rows(self, lo: int = 0, hi: Optional[int] = None):
+        return self._graph.long_rows(self._t, lo, hi)
+
+
 class FeatureShardedAggregation:
     """Column-sharded aggregation: see the module docstring.
 
     graph / val: the FULL structure and attention values (replicated on every rank).
-    rank, world, cuts: this rank, the group size and the head-row cut points used for the row layout
-    (``shard_bounds``); d: full feature width (must divide by world)."""
+    rank, world, cuts: this rank, the group size and the row cut points of the row layout (rank i owns rows
+    [cuts[i], cuts[i+1]) of every N-row table in the row-block layout); d: full feature width, a multiple of world
+    (``slab_width`` pads other widths).
+
+    Layouts:  column slab  [N, D/G]         all rows, this rank's columns (what the SpMM works on);
+              row block    [G, rows_r, D/G] this rank's rows as G column panels (panel i = the columns of rank i) --
+                                            what leaves for / arrives from the other ranks, one panel per peer.
+
+    The two exchanges of a pass are pipelined with the SpMM from both ends (``exchange_aggregate``):
+      * IN  (row block -> column slab): the panels leave in BATCHES of peer offsets, all batches queued at once; the SpMM
+        runs part by part -- part b = the entries that gather from the rows of batch b (``KGStructure.structure_parts``),
+        accumulating onto the parts before it -- so the SpMM of part b runs while batch b + 1 is on the links;
+      * OUT (column slab -> row block): the LAST part runs owner range by owner range, every finished range leaves
+        point-to-point while the next one is computed.
+    """
 
     def __init__(self, graph: KGStructure, val: torch.Tensor, rank: int, world: int, d: int, cuts: List[int],
                  spmm: Optional[Callable] = None, permute: Optional[Callable] = None, group=None):
@@ -98,15 +123,75 @@ class FeatureShardedAggregation:
             from . import ops
             spmm, permute = ops.spmm_raw, ops.permute_values
         if d % world:
-            raise ValueError(f"feature width {d} does not divide over {world} ranks")
-        self.spmm, self.graph, self.val = spmm, graph, val
-        self.val_t = permute(val, graph.t_perm)
+            raise ValueError(f"feature width {d} does not divide over {world} ranks (pad it: slab_width)")
+        self.spmm, self.permute, self.graph = spmm, permute, graph
         self.rank, self.world, self.d, self.dg = rank, world, d, d // world
         self.cuts = [int(c) for c in cuts]
+        if len(self.cuts) != world + 1 or self.cuts[0] != 0 or self.cuts[-1] != graph.n:
+            raise ValueError("row cuts must run from 0 to the number of entities, one range per rank")
         self.rows = [self.cuts[i + 1] - self.cuts[i] for i in range(world)]
         self.my_rows = self.rows[rank]
         self.group = group
+        self._parts = {}              # (transposed, batches) -> (StructureParts, their values)
+        self.bytes_sent = 0           # payload bytes this rank handed to the collective library (tests count them)
+        self.set_values(val)
 
+    @staticmethod
+    def slab_width(d: int, world: int) -> int:
+        """Columns per rank for a table of d columns: ceil(d / world); the table is padded with zero columns to
+        world * slab_width (the reference's default embed_dim = 300 on 8 GPUs: 38 columns per rank, 304 in all)."""
+        return -(-int(d) // int(world))
+
+    def set_values(self, val: torch.Tensor):
+        """New attention values (an update_att): the CSC copy and the parts' copies follow."""
+        self.val = val
+        g = self.graph
+        self.val_t = self.permute(val, g.t_perm) if g.t_perm is not None else None
+        for key, (parts, _) in list(self._parts.items()):
+            self._parts[key] = (parts, [self.permute(val, p.perm) for p in parts])
+
+    # ------------------------------------------------------------------ parts of the structure by source block
+    @staticmethod
+    def offset_batches(world: int, n_batches: Optional[int] = None) -> List[List[int]]:
+        """Peer offsets k = 0 .. G-1 (the block of rank (r - k) % G arrives at rank r; k = 0 is r's own block) grouped
+        into the batches of the part-wise SpMM.  Every rank sends and receives exactly one block per offset, so every
+        batch loads all links alike.  Batch 0 = the own block + the first peer (the SpMM starts after 1/(G-1) of the
+        exchange); the other offsets in equal groups."""
+        if n_batches is None:
+            n_batches = 1 if world < 3 else 3
+        n_batches = max(1, min(n_batches, world))
+        if n_batches == 1:
+            return [list(range(world))]
+        first = [0, 1] if world > n_batches else [0]
+        rest = list(range(len(first), world))
+        per = [len(rest) // (n_batches - 1) + (1 if i >= (n_batches - 1) - len(rest) % (n_batches - 1) else 0)
+               for i in range(n_batches - 1)]
+        out, o = [first], 0
+        for c in per:
+            out.append(rest[o:o + c])
+            o += c
+        return [b for b in out if b]
+
+    def parts(self, transposed: bool, n_batches: Optional[int] = None):
+        """(offset batches, one StructurePart per batch, its values): the CSR (transposed: the CSC) cut by the block its
+        entries gather from; built once per (direction, batching) and kept."""
+        batches = self.offset_batches(self.world, n_batches)
+        key = (bool(transposed), tuple(tuple(b) for b in batches))
+        if key not in self._parts:
+            part_of_block = [0] * self.world
+            for b, ks in enumerate(batches):
+                for k in ks:
+                    part_of_block[(self.rank - k) % self.world] = b
+            parts = self.graph.structure_parts(transposed, self.cuts, part_of_block)
+            assert len(parts) == len(batches)
+            self._parts[key] = (parts, [self.permute(self.val, p.perm) for p in parts])
+        parts, vals = self._parts[key]
+        return batches, parts, vals
+
+    def head_parts(self, n_batches: Optional[int] = None):
+        return self.parts(True, n_batches)
+
+    # ------------------------------------------------------------------ the SpMM alone (no communication)
     def column_slab(self, table: torch.Tensor) -> torch.Tensor:
         return table[:, self.rank * self.dg:(self.rank + 1) * self.dg].contiguous()
 
@@ -120,30 +205,113 @@ class FeatureShardedAggregation:
         g = self.graph
         return self.spmm(g.t_rowptr, g.t_col, self.val_t, grad_slab, g.n, out=out, long_rows=g.long_rows(True))
 
-    def forward_to_row_block(self, slab: torch.Tensor, side_slab: Optional[torch.Tensor] = None,
-                             out: Optional[torch.Tensor] = None, pieces: Optional[int] = None):
-        """forward() fused with to_row_block(): the SpMM runs head-row range by head-row range, and as soon as a
-        piece of the rows owned by rank j is done it leaves for rank j (point-to-point, RCCL's stream, one xGMI
-        link per peer) while the next piece is being aggregated.  Every peer's range is cut into `pieces` parts
-        and the parts are visited peer-major inside a part index, so all 7 links are busy from the first round
-        on and only the LAST part of one peer (1 / (G * pieces) of the traffic) is exposed after the SpMM ends.
-        Part p of round k computes rows of rank (rank + k) % G and receives from rank (rank - k) % G.
-        Returns (side_slab [N, D/G], row_block [G, rows_g, D/G]).
+    # ------------------------------------------------------------------ SpMM pipelined with its exchanges
+    def _staged(self, t: torch.Tensor) -> bool:
+        """gloo moves host memory only: device tensors are staged through the host (1-GPU rehearsal of the N > 1 path)"""
+        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
+
+    def exchange_aggregate(self, transposed: bool, slab: Optional[torch.Tensor] = None,
+                           block_in: Optional[torch.Tensor] = None, plus_self: bool = False, exchange_out: bool = True,
+                           n_batches: Optional[int] = None, pieces: Optional[int] = None,
+                           side_slab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """side = A x (transposed: A^T x) on this rank's columns with both layout exchanges folded in.
+          input   ``slab`` [N, D/G] (already a column slab: one whole-structure pass), or ``block_in`` [G, rows_r, D/G]
+                  (this rank's rows as panels: they leave in offset batches and the SpMM runs part by part behind them);
+          output  exchange_out: (side_slab, row block [G, rows_r, D/G]) -- the last part leaves owner range by owner range
+                  (each range in ``pieces`` pieces); otherwise side_slab [N, D/G] alone.
+        plus_self: side = x + A x (the layer's ``ego + side``, model.py:109)."""
+        g, r, G = self.graph, self.rank, self.world
+        if (slab is None) == (block_in is None):
+            raise ValueError("exchange_aggregate: exactly one of slab / block_in")
+        src = slab if slab is not None else block_in
+        dev, dtype = src.device, src.dtype
+        whole = _Whole(g, transposed)
+        if block_in is not None and G > 1:
+            if tuple(block_in.shape) != (G, self.my_rows, self.dg):
+                raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected {(G, self.my_rows, self.dg)}")
+            batches, parts, vals = self.parts(transposed, n_batches)
+            slab = torch.empty((g.n, self.dg), dtype=dtype, device=dev)
+            slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # offset 0: no transfer
+            staged = self._staged(block_in)
+            queued = []
+            for ks in batches:               # ALL batches are queued now, in order, on the collective library's stream
+                ops_, host = [], []
+                for k in ks:
+                    if k == 0:
+                        continue
+                    j, i = (r + k) % G, (r - k) % G
+                    if self.my_rows:
+                        ops_.append(dist.P2POp(dist.isend, block_in[j].cpu() if staged else block_in[j], j, self.group))
+                        self.bytes_sent += block_in[j].numel() * block_in.element_size()
+                    if self.rows[i]:
+                        dst = slab[self.cuts[i]:self.cuts[i + 1]]
+                        rcv = torch.empty(dst.shape, dtype=dtype) if staged else dst
+                        if staged:
+                            host.append((rcv, dst))
+                        ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
+                queued.append((dist.batch_isend_irecv(ops_) if ops_ else [], host))
+        else:
+            if block_in is not None:         # one rank: the row block IS the slab
+                slab = block_in[0]
+            parts = [whole]
+            vals = [self.val_t if transposed else self.val]
+            queued = [([], [])]
+        if side_slab is None:
+            side_slab = torch.empty((g.n, self.dg), dtype=dtype, device=dev)
+        live = [b for b, p in enumerate(parts) if p.nnz > 0] or [0]
+        first = True
+
+        def arrived(b):
+            works, host = queued[b]
+            for w in works:
+                w.wait()
+            for rcv, dst in host:
+                dst.copy_(rcv)
+            queued[b] = ([], [])
+
+        for b in range(len(parts)):
+            arrived(b)
+            if b not in live:
+                continue
+            part, val_p = parts[b], vals[b]
+            if b == live[-1]:                # the last pass: x itself is added here (plus_self), when ALL of it has arrived
+                for later in range(b + 1, len(parts)):
+                    arrived(later)
+            add_self = slab if (plus_self and b == live[-1]) else None
+            if b == live[-1] and exchange_out and G > 1:
+                out = self._ranges_to_row_block(part, val_p, slab, side_slab, first, add_self, out, pieces)
+            else:
+                self.spmm(part.rowptr, part.col, val_p, slab, g.n, out=side_slab, long_rows=part.long_rows(),
+                          add_self=add_self, add2=None if first else side_slab)
+            first = False
+        if not exchange_out:
+            return side_slab
+        if G == 1:
+            if out is None:
+                out = torch.empty((1, self.my_rows, self.dg), dtype=dtype, device=dev)
+            out[0].copy_(side_slab)
+        return side_slab, out
+
+    def _ranges_to_row_block(self, part, val_p, slab, side_slab, first, add_self, out, pieces):
+        """The last SpMM pass of ``exchange_aggregate`` fused with the slab -> row block exchange: the pass runs owner
+        range by owner range, and as soon as a piece of the rows owned by rank j is done it leaves for rank j
+        (point-to-point, the collective library's stream, one xGMI link per peer) while the next piece is being aggregated.
+        Every peer's range is cut into `pieces` pieces visited peer-major inside a piece index, so all links are busy from
+        the first round on and only the LAST piece of one peer (1 / (G * pieces) of the traffic) is exposed after the
+        SpMM ends.  Piece p of round k computes rows of rank (rank + k) % G and receives from rank (rank - k) % G.
 
         On the GPU the row-range launches alternate between two side streams: back to back on ONE stream every extra
         launch costs ~25 us of tail and gap (5 M rows x 100 M entries x 32 columns: 1 launch 2.16 ms, 8: 2.30,
         32: 2.94), on two alternating streams the tail of one overlaps the start of the next (32 launches: 2.25 ms)
-        and each part still completes -- and leaves -- in order."""
-        g = self.graph
+        and each piece still completes -- and leaves -- in order."""
+        r, G = self.rank, self.world
         if pieces is None:
             pieces = 4
-        if side_slab is None:
-            side_slab = torch.empty((g.n, self.dg), dtype=slab.dtype, device=slab.device)
         if out is None:
-            out = torch.empty((self.world, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
-        staged = slab.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"   # host-only transport
+            out = torch.empty((G, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
+        staged = self._staged(slab)
 
-        def part(lo, hi, p):      # p-th of `pieces` sub-ranges of [lo, hi)
+        def piece(lo, hi, p):      # p-th of `pieces` sub-ranges of [lo, hi)
             n = hi - lo
             return lo + n * p // pieces, lo + n * (p + 1) // pieces
 
@@ -157,24 +325,27 @@ class FeatureShardedAggregation:
                 st.wait_stream(main)
         works, host, step = [], [], 0
         for p in range(pieces):
-            for k in range(self.world):
-                j, i = (self.rank + k) % self.world, (self.rank - k) % self.world
-                lo, hi = part(self.cuts[j], self.cuts[j + 1], p)
+            for k in range(G):
+                j, i = (r + k) % G, (r - k) % G
+                lo, hi = piece(self.cuts[j], self.cuts[j + 1], p)
                 ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
                 step += 1
-                with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this part
+                with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this piece
                     if hi > lo:
-                        self.spmm(g.rowptr[lo:hi + 1], g.col, self.val, slab, hi - lo, out=side_slab[lo:hi],
-                                  long_rows=g.long_rows(False, lo, hi))
+                        self.spmm(part.rowptr[lo:hi + 1], part.col, val_p, slab, hi - lo, out=side_slab[lo:hi],
+                                  long_rows=part.long_rows(lo, hi),
+                                  add_self=add_self[lo:hi] if add_self is not None else None,
+                                  add2=None if first else side_slab[lo:hi])
                     if k == 0:
-                        mlo, mhi = part(0, self.my_rows, p)
-                        out[self.rank, mlo:mhi].copy_(side_slab[lo:hi])
+                        mlo, mhi = piece(0, self.my_rows, p)
+                        out[r, mlo:mhi].copy_(side_slab[lo:hi])
                         continue
-                    rlo, rhi = part(0, self.my_rows, p)          # the matching part of MY rows, arriving from rank i
+                    rlo, rhi = piece(0, self.my_rows, p)          # the matching piece of MY rows, arriving from rank i
                     ops_ = []
                     if hi > lo:
                         snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
                         ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
+                        self.bytes_sent += (hi - lo) * self.dg * side_slab.element_size()
                     if rhi > rlo:
                         if staged:
                             rcv = torch.empty((rhi - rlo, self.dg), dtype=out.dtype)
@@ -191,15 +362,24 @@ class FeatureShardedAggregation:
             w.wait()
         for rcv, i, rlo, rhi in host:
             out[i, rlo:rhi].copy_(rcv)
-        return side_slab, out
+        return out
+
+    def forward_to_row_block(self, slab: torch.Tensor, side_slab: Optional[torch.Tensor] = None,
+                             out: Optional[torch.Tensor] = None, pieces: Optional[int] = None):
+        """forward() fused with to_row_block(): (side_slab [N, D/G], row block [G, rows_r, D/G]); the slab -> row block
+        exchange hidden behind the SpMM (``_ranges_to_row_block``)."""
+        if self.world == 1:
+            side_slab = self.forward(slab, out=side_slab)
+            return side_slab, self.to_row_block(side_slab, out=out)
+        return self.exchange_aggregate(False, slab=slab, exchange_out=True, pieces=pieces, side_slab=side_slab, out=out)
 
     def backward_from_row_block(self, block: torch.Tensor, out: Optional[torch.Tensor] = None,
                                 pieces: Optional[int] = None) -> torch.Tensor:
-        """to_column_slab() fused with backward(): the gradient row block [G, rows_g, D/G] goes back to the column
-        layout in `pieces` COLUMN pieces (every column of A^T g is independent), all exchanges queued at once on the
-        collective's stream, and the transpose SpMM of piece p runs while piece p + 1 is still on the links.  A piece
-        is never narrower than 32 columns (128-byte gathers; narrower rows cost the same time per entry), so the
-        exchange of the N = 8 case (D/G = 32) stays in one piece.  Returns grad_ego[:, my columns]."""
+        """to_column_slab() fused with backward(): grad_ego[:, my columns] from the gradient row block [G, rows_r, D/G].
+        Slabs of >= 64 columns go back in COLUMN pieces (every column of A^T g is independent): all exchanges queued at
+        once on the collective's stream, the transpose SpMM of piece p runs while piece p + 1 is still on the links.  A
+        piece is never narrower than 32 columns (128-byte gathers; narrower rows cost the same time per entry), so
+        narrower slabs (N = 8: D/G = 32) go back in head-range batches instead (``backward_in_head_parts``)."""
         g = self.graph
         if pieces is None:
             pieces = max(1, min(4, self.dg // 32))
@@ -207,16 +387,19 @@ class FeatureShardedAggregation:
             pieces -= 1
         if out is None:
             out = torch.empty((g.n, self.dg), dtype=block.dtype, device=block.device)
-        if self.world == 1 or pieces == 1:
+        if self.world == 1:
             return self.backward(self.to_column_slab(block), out=out)
+        if pieces == 1:
+            return self.backward_in_head_parts(block, out=out)
         w = self.dg // pieces
-        staged = block.is_cuda and dist.get_backend(self.group) == "gloo"     # host-only transport (rehearsal)
+        staged = self._staged(block)
         queue = []
         for p in range(pieces):
             src = block[:, :, p * w:(p + 1) * w].contiguous().view(self.world * self.my_rows, w)
             dst = torch.empty((g.n, w), dtype=block.dtype, device=block.device)
+            self.bytes_sent += (self.world - 1) * self.my_rows * w * block.element_size()
             if staged or not block.is_cuda:
-                self._all_to_all(dst, src, self.rows, [self.my_rows] * self.world)
+                self._all_to_all(dst, src, self.rows, [self.my_rows] * self.world, count=False)
                 work = None
             else:
                 work = dist.all_to_all_single(dst, src, output_split_sizes=self.rows,
@@ -230,8 +413,22 @@ class FeatureShardedAggregation:
                       long_rows=g.long_rows(True))
         return out
 
+    def backward_in_head_parts(self, block: torch.Tensor, out: Optional[torch.Tensor] = None,
+                               n_batches: Optional[int] = None) -> torch.Tensor:
+        """to_column_slab() fused with backward() when the slab is too narrow to cut by columns (N = 8: D/G = 32).
+        A^T g = sum_b A_b^T g, A_b = the entries whose HEAD lies in the row blocks of offset batch b: the blocks leave in
+        batches (point-to-point, every batch loads all links alike, all of them queued at once on the collective's
+        stream), and the transpose SpMM of part b -- a launch of the same kernel over the sub-CSC of part b, accumulating
+        onto the sum of the parts before it (``add2``) -- runs while batch b + 1 is on the links.  Exposed: the first
+        batch (one peer block) instead of the whole exchange; price: one more read of the N x D/G result per extra
+        part.  Returns grad_ego[:, my columns]."""
+        if n_batches is None and self.world >= 3:
+            n_batches = 3
+        return self.exchange_aggregate(True, block_in=block, exchange_out=False, n_batches=n_batches, side_slab=out)
+
+    # ------------------------------------------------------------------ the plain exchanges
     def to_row_block(self, slab: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """N x D/G column slab -> this rank's rows as G column panels, shape [G, rows_g, D/G]
+        """N x D/G column slab -> this rank's rows as G column panels, shape [G, rows_r, D/G]
         (panel i = columns of rank i).  One all-to-all."""
         if out is None:
             out = torch.empty((self.world, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
@@ -242,7 +439,7 @@ class FeatureShardedAggregation:
         return out
 
     def to_column_slab(self, block: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """[G, rows_g, D/G] panels of this rank's rows -> the N x D/G slab of this rank's columns."""
+        """[G, rows_r, D/G] panels of this rank's rows -> the N x D/G slab of this rank's columns."""
         if out is None:
             out = torch.empty((self.graph.n, self.dg), dtype=block.dtype, device=block.device)
         if self.world == 1:
@@ -251,7 +448,9 @@ class FeatureShardedAggregation:
         self._all_to_all(out, block.view(self.world * self.my_rows, self.dg), self.rows, [self.my_rows] * self.world)
         return out
 
-    def _all_to_all(self, out, inp, out_splits, in_splits):
+    def _all_to_all(self, out, inp, out_splits, in_splits, count=True):
+        if count:
+            self.bytes_sent += (sum(in_splits) - in_splits[self.rank]) * inp.shape[1] * inp.element_size()
         if inp.is_cuda and dist.get_backend(self.group) == "gloo":
             # gloo moves host memory only (single-GPU rehearsal of the N>1 path): stage through the host
             host_out = torch.empty(out.shape, dtype=out.dtype)

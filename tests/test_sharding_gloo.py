@@ -11,12 +11,16 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def cpu_spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, add_self=None):
+def cpu_spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, add_self=None, add2=None):
     rp = rowptr.long()
     lo, hi = int(rp[0]), int(rp[-1])
     rows = torch.repeat_interleave(torch.arange(n_rows), rp[1:] - rp[:-1])
     res = torch.zeros((n_rows, x.shape[1]), dtype=x.dtype)
     res.index_add_(0, rows, val[lo:hi, None] * x[col[lo:hi].long() - x_row_offset])
+    if add_self is not None:
+        res = res + add_self
+    if add2 is not None:
+        res = res + add2
     if out is not None:
         out.copy_(res)
         return out
@@ -98,13 +102,35 @@ def _feature_worker(rank, world, port, n, d, q):
         for pieces in (None, 2, 3):                                    # exchange in column pieces, SpMM per piece
             gego2 = fs.backward_from_row_block(gblock, pieces=pieces)
             ok &= torch.allclose(gego2, gego, rtol=1e-6, atol=1e-6)
+        # exchange in head-range batches, the transpose SpMM part by part behind them (the N = 8 form: D/G too narrow to
+        # cut by columns) -- the parts partition the CSC's entries, every batch moves one block per offset
+        for nb in (None, 1, 2, 3, world):
+            before = fs.bytes_sent
+            gego3 = fs.backward_in_head_parts(gblock, n_batches=nb)
+            ok &= torch.allclose(gego3, gego, rtol=1e-5, atol=1e-5)
+            ok &= fs.bytes_sent - before == 4 * fs.dg * (hi - lo) * (world - 1)       # my rows, once to every peer
+            batches, parts, vals = fs.head_parts(nb)
+            ok &= sorted(k for b in batches for k in b) == list(range(world))
+            ok &= sum(p.nnz for p in parts if p is not None) == g.nnz
+        # both exchanges folded into the pass (the integrated step's aggregation): my rows in as panels, my rows out
+        for transposed, src in ((False, x), (True, gside)):
+            blk_in = torch.stack([src[lo:hi, i * fs.dg:(i + 1) * fs.dg] for i in range(world)]).contiguous()
+            for plus_self in (False, True):
+                for nb in (None, 1, 2):
+                    _, blk_out = fs.exchange_aggregate(transposed, block_in=blk_in, plus_self=plus_self, n_batches=nb, pieces=3)
+                    want_full = torch.matmul(a.t() if transposed else a, src) + (src if plus_self else 0)
+                    got = torch.cat([blk_out[i] for i in range(world)], dim=1)
+                    ok &= torch.allclose(got, want_full[lo:hi], rtol=1e-5, atol=1e-4)
+        val2 = val * 0.5                                               # an attention refresh reaches the parts' values
+        fs.set_values(val2)
+        ok &= torch.allclose(fs.backward_in_head_parts(gblock), 0.5 * gego, rtol=1e-5, atol=1e-5)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_feature_sharded_forward_exchange_backward(world):
     import __graft_entry__ as ge
     ge.build()
