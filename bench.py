@@ -282,7 +282,45 @@ def whole_path_timings(h, t, r, n, d, dev):
     out["default_architecture_step"] = default_arch_step_timing(h, t, r, n, dev)
     torch.cuda.empty_cache()
     out["main_py_default_architecture_step"] = default_arch_step_timing(h, t, r, n, dev, main_py=True)
+    torch.cuda.empty_cache()
+    out["c4_regime_spmm"] = c4_regime_timing(d, dev)
     return out
+
+
+def c4_regime_timing(d, dev, n=5_000_000, e=100_000_000):
+    """The SpMM pair where NOTHING fits a cache (BASELINE config[3]'s graph on one GPU: a 5 GB source table, 20 entries
+    per row): what one rank of the row-range scheme runs per 1/N of the rows.  Graph drawn on the device (zipf heads)."""
+    import literalkg_amd as L
+    from literalkg_amd import ops
+    from literalkg_amd.synth import make_kg_device
+    h, t, r = make_kg_device(n, e, "zipf", 2022, dev)
+    g = L.KGStructure.from_triples(n, h, t, r, device=dev)
+    del h, t, r
+    val = torch.rand(g.nnz, device=dev)
+    val_t = ops.permute_values(val, g.t_perm)
+    x = torch.randn((n, d), device=dev) * 0.05
+    out = torch.empty((n, d), device=dev)
+
+    def ev_time(fn, reps=8):
+        for _ in range(2):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in evs]))
+    fwd = ev_time(lambda: ops.spmm_raw(g.rowptr, g.col, val, x, n, out=out, long_rows=g.long_rows(False)))
+    bwd = ev_time(lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, n, out=out, long_rows=g.long_rows(True)))
+    by = algorithmic_bytes(g.nnz, n, d)
+    res = {"config": f"{n} entities / {g.nnz} stored entries, D={d}, one GPU (zipf heads drawn on the device, unclipped)",
+           "algorithmic_bytes": by, "fwd_ms": fwd, "bwd_ms": bwd,
+           "fwd_frac_of_hbm_roofline": by / fwd / 1e6 / HBM_PEAK_GBS, "bwd_frac_of_hbm_roofline": by / bwd / 1e6 / HBM_PEAK_GBS,
+           "edges_per_s": 2 * g.nnz / (fwd + bwd) * 1e3}
+    del g, val, val_t, x, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def gate_timing(n, d, dev):
@@ -362,10 +400,12 @@ def sharded_step_timings(world, rank, dev, n_glob, d, h_own, t_own, r_own, steps
             loss.backward()
             model.sync_gradients()
             opt.step()
+        from literalkg_amd import distributed as D
         for _ in range(2):
             step()
         dist.barrier()
         torch.cuda.synchronize()
+        D.TRAFFIC.clear()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -373,7 +413,8 @@ def sharded_step_timings(world, rank, dev, n_glob, d, h_own, t_own, r_own, steps
         torch.cuda.synchronize()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64).to(cdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        out[scheme] = {"ms_per_step": float(el) / steps * 1e3, "steps": steps}
+        out[scheme] = {"ms_per_step": float(el) / steps * 1e3, "steps": steps,
+                       "bytes_sent_per_step_rank0": {k: v // steps for k, v in sorted(D.TRAFFIC.items())}}
         del model, opt, local
         torch.cuda.empty_cache()
     out["config"] = f"ShardedLiteralKG gcn x1, D={d}, TransR, dropout 0.1, batch 2049 triples, {n_glob} entities over {world} ranks"
@@ -703,7 +744,8 @@ def main():
         total = res["total_entries"]
         achieved = res["fwd_bytes"] / (res["fwd_ms"] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(res["fwd_bytes"], args.skew) if world == 1 else (None, "N > 1: not collected")
-        workload = (f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
+        workload = ((f"[value = scheme '{kind}'] " if world > 1 else "") +
+                    f"1 aggregation (GAT) layer, D={d}: SpMM forward + transpose-SpMM backward"
                     + {"none": "", "rows": " + RCCL all-reduce of the entity-gradient table",
                        "features": " + RCCL exchange (column slab <-> row block) both ways"}[kind]
                     + f"; synthetic KG {n_glob} entities / {total} stored (h,t) entries "
@@ -758,6 +800,22 @@ def main():
                 for k, v in results.items() if k.startswith("features")}
             if "pipelined_exchange_error" in results["features"]:
                 out["features_exchanges"]["pipelined_exchange_error"] = results["features"]["pipelined_exchange_error"]
+        if world > 1:
+            # both schemes at the top level: `value` is the scheme named in config.value_scheme; the north star's edge-range
+            # sharding + gradient all-reduce (BASELINE.json configs[3]) is `value_rows`, the column-sharded scheme `value_features`
+            for k_, name_ in (("rows", "value_rows"), (head if head.startswith("features") else "features", "value_features")):
+                if k_ in results:
+                    out[name_] = 2 * results[k_]["total_entries"] * args.steps / results[k_]["elapsed"]
+            out["config"]["value_scheme"] = kind
+            out["config"]["sharding_rows"] = f"head-row ranges x{world}, replicated table, RCCL all-reduce of the entity-gradient table"
+            out["config"]["sharding_features"] = (f"feature columns x{world} (D/G={d // world}), replicated structure, column slab "
+                                                  f"<-> row block exchange pipelined with the SpMM")
+            out["n_ranks_seen"] = dist.get_world_size()
+            try:
+                out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as exc:   # noqa: BLE001 -- informational only
+                out["rccl_version"] = f"unavailable ({type(exc).__name__})"
+            out["collective_backend"] = dist.get_backend()
         if "rows" in results and kind != "rows":      # the north star's scheme, same graph shape, next to the headline
             rr = results["rows"]
             out["rows_scheme"] = {

@@ -39,6 +39,11 @@ typedef enum {
 /* library version: major*10000 + minor*100 + patch */
 int lkg_version(void);
 const char *lkg_last_error(void);
+/* Load every code object of the library on the CURRENT device now.  HIP loads a translation unit's device code on the first
+ * launch of one of its kernels -- tens of milliseconds that would otherwise land inside the first call that needs them (the
+ * reference's first mode='update_att', main_pretraining.py:139: a dozen sort / scan kernels of the structure build).  The
+ * Python binding calls it once per process, before the first entry point that takes a stream.  No launch, no allocation. */
+int lkg_preload(void);
 
 /* ------------------------------------------------------------------ host --
  * KG structure build.  Replaces the per-relation torch.where / cat / stack /

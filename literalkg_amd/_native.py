@@ -11,6 +11,7 @@ i64, i32, f32, vp, u64 = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_uint64
 PROTOTYPES = {
     "lkg_version": [],
     "lkg_last_error": [],
+    "lkg_preload": [],
     "lkg_csr_build": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_csr_transpose": [i64, i64, i64, vp, vp, vp, vp, vp],
     "lkg_row_partition": [i64, vp, i32, vp],
@@ -113,8 +114,29 @@ def load():
     return lib
 
 
+_preloaded = False
+
+
+def preload():
+    """Load the library's code objects on the current device once per process (include/literalkg_hip.h: lkg_preload), as soon
+    as torch has a HIP context -- so that no later call pays for it inside a timed region."""
+    global _preloaded
+    if _preloaded:
+        return
+    import torch
+    if not torch.cuda.is_initialized():
+        return                       # (host-only entry points -- structure build on the CPU, file parsing -- need no device code)
+    _preloaded = True
+    lib = load()
+    if lib.lkg_preload() != 0:
+        msg = lib.lkg_last_error()
+        raise LkgError(f"lkg_preload failed: {msg.decode() if msg else '?'}")
+
+
 def call(name, *args):
     lib = load()
+    if not _preloaded:
+        preload()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.lkg_last_error()

@@ -304,3 +304,10 @@ extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t 
     hipStream_t s = (hipStream_t)stream;
     return vec ? dispatch<float4>(a, s) : dispatch<float>(a, s);
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_attention() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&extra_relations_kernel<float4>)) == hipSuccess ? 0 : 1;
+}

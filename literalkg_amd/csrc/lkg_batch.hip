@@ -409,3 +409,10 @@ extern "C" int lkg_sample_kg_batch(int64_t n_groups, int32_t neg_rate, uint64_t 
     LKG_CHECK_LAUNCH("lkg_sample_kg_batch");
     return LKG_OK;
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_batch() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&group_by_key_kernel)) == hipSuccess ? 0 : 1;
+}

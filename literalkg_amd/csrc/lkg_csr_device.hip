@@ -407,3 +407,10 @@ extern "C" int lkg_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t 
     LKG_CHECK_LAUNCH("lkg_csr_transpose_device");
     return LKG_OK;
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_csr_device() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&scan_totals_kernel)) == hipSuccess ? 0 : 1;
+}

@@ -701,3 +701,10 @@ extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_
     LKG_REQUIRE(tiles < INT32_MAX, "lkg_grouped_gemm_f32: too many tiles");
     return run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)n_groups), (hipStream_t)stream);
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_gemm() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&presplit_b_kernel)) == hipSuccess ? 0 : 1;
+}

@@ -945,3 +945,10 @@ extern "C" int lkg_gemm_skinny_f32(int64_t m, int64_t n, int64_t k, const float 
     LKG_CHECK_LAUNCH("lkg_gemm_skinny_f32");
     return LKG_OK;
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_gemm_wgrad() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&wgrad_f16x2_kernel)) == hipSuccess ? 0 : 1;
+}

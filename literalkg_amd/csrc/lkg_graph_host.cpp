@@ -32,6 +32,25 @@ void lkg_set_error(const char *fmt, ...) {
 extern "C" const char *lkg_last_error(void) { return g_err; }
 extern "C" int lkg_version(void) { return 100; /* 0.1.0 */ }
 
+int lkg_internal_preload_spmm();
+int lkg_internal_preload_attention();
+int lkg_internal_preload_batch();
+int lkg_internal_preload_csr_device();
+int lkg_internal_preload_gemm();
+int lkg_internal_preload_gemm_tall();
+int lkg_internal_preload_gemm_wgrad();
+int lkg_internal_preload_rowwise();
+int lkg_internal_preload_score();
+
+extern "C" int lkg_preload(void) {
+    const int failed = lkg_internal_preload_spmm() + lkg_internal_preload_attention() + lkg_internal_preload_batch() + lkg_internal_preload_csr_device() + lkg_internal_preload_gemm() + lkg_internal_preload_gemm_tall() + lkg_internal_preload_gemm_wgrad() + lkg_internal_preload_rowwise() + lkg_internal_preload_score();
+    if (failed) {
+        lkg_set_error("lkg_preload: %d of the library's code objects could not be loaded on the current device", failed);
+        return LKG_ERR_HIP;
+    }
+    return LKG_OK;
+}
+
 namespace {
 template <class F>
 void parallel_rows(int64_t n, F &&fn) {

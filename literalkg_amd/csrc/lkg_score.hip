@@ -450,3 +450,10 @@ extern "C" int lkg_dot_score_bwd_f32(int64_t batch, int32_t dim, const float *em
     LKG_CHECK_LAUNCH("lkg_dot_score_bwd_f32");
     return LKG_OK;
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_score() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&loss_reduce_kernel)) == hipSuccess ? 0 : 1;
+}

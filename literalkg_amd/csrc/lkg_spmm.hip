@@ -749,3 +749,10 @@ extern "C" int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int
     LKG_CHECK_LAUNCH("lkg_spmm_csr_scatter_bwd_f32");
     return LKG_OK;
 }
+
+// lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
+// attributes is such a use (no launch).
+int lkg_internal_preload_spmm() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&permute_kernel)) == hipSuccess ? 0 : 1;
+}

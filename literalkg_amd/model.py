@@ -138,8 +138,6 @@ class Aggregator(nn.Module):
         """mod(residual_connection(hi)), with the identity mapping folded into the Linear's weight on the device path."""
         if not self.use_residual:
             return self._lin(mod, hi)
-        if not hi.is_cuda:
-            return self._lin(mod, self.residual_connection(hi, h0, lamda, alpha, l))
         h0p = self.h0_projection if self.h0_projection is not None else \
             ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
         return self._lin_mapped(mod, ops.axpby(hi, h0p, 1 - alpha, alpha), self._identity_map(lamda, l))
@@ -187,22 +185,18 @@ class Aggregator(nn.Module):
                 z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
             return self._finish(z)
         if kind == "bi-interaction":
-            if ego.is_cuda:
-                # sum, product and (with the residual) both mixes (1 - a) hi + a linear_h0(h0) in ONE kernel, one for their
-                # backward; the identity-mapping matrix (1 - b) + b W once for both branches
-                h0p = None
-                if self.use_residual:
-                    h0p = self.h0_projection if self.h0_projection is not None else \
-                        ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
-                ms, mp = ops.bi_mix(ego, side, h0p, alpha)
-                if self.use_residual:
-                    wp = self._identity_map(lamda, l)
-                    s, b = self._lin_mapped(self.linear1, ms, wp), self._lin_mapped(self.linear2, mp, wp)
-                else:
-                    s, b = self._lin(self.linear1, ms), self._lin(self.linear2, mp)
-                return self._finish(ops.leaky_relu_sum(b, s), slope=1.0)
-            s = self._lin(self.linear1, self.residual_connection(ops.axpby(ego, side), h0, lamda, alpha, l))
-            b = self._lin(self.linear2, self.residual_connection(ops.mul(ego, side), h0, lamda, alpha, l))
+            # sum, product and (with the residual) both mixes (1 - a) hi + a linear_h0(h0) in ONE kernel, one for their
+            # backward; the identity-mapping matrix (1 - b) + b W once for both branches
+            h0p = None
+            if self.use_residual:
+                h0p = self.h0_projection if self.h0_projection is not None else \
+                    ops.linear(h0, self.linear_h0.weight, self.linear_h0.bias)
+            ms, mp = ops.bi_mix(ego, side, h0p, alpha)
+            if self.use_residual:
+                wp = self._identity_map(lamda, l)
+                s, b = self._lin_mapped(self.linear1, ms, wp), self._lin_mapped(self.linear2, mp, wp)
+            else:
+                s, b = self._lin(self.linear1, ms), self._lin(self.linear2, mp)
             # LeakyReLU is applied per branch BEFORE the sum (model.py:125-130): one kernel, then a slope-1
             # epilogue for the LayerNorm
             return self._finish(ops.leaky_relu_sum(b, s), slope=1.0)
@@ -238,6 +232,7 @@ class LiteralKG(nn.Module):
         self.use_pretrain = args.use_pretrain
         self.device = args.device
         self.n_entities, self.n_relations = n_entities, n_relations
+        self.id_space = n_entities        # ids callers may hand in: [0, id_space) (a row-sharded module: the GLOBAL entity count)
         self.embed_dim, self.relation_dim = args.embed_dim, args.relation_dim
         self.scale_gat_dim = args.scale_gat_dim
         self.use_residual, self.alpha, self.lamda = args.use_residual, args.alpha, args.lamda
@@ -357,7 +352,7 @@ class LiteralKG(nn.Module):
                  and isinstance(att, AttentionCSR))
         kept = [cur]
         res_layers = [layer for layer in self.aggregator_layers if layer.use_residual]
-        if len(res_layers) > 1 and cur.is_cuda:      # every layer projects the SAME h0 (model.py:93): one stacked product
+        if len(res_layers) > 1:      # every layer projects the SAME h0 (model.py:93): one stacked product
             projections = ops.stacked_linear(cur, [layer.linear_h0.weight for layer in res_layers],
                                              [layer.linear_h0.bias for layer in res_layers])
             for layer, proj in zip(res_layers, projections):
@@ -474,7 +469,7 @@ class LiteralKG(nn.Module):
     def calc_triplet_loss(self, h, r, pos_t, neg_t):
         # generate_kg_batch repeats every sampled (h, r, t+) pre_training_neg_rate times (dataloader.py:318-330): such
         # a batch projects h and t+ once per group.  Checked on the ids (any other batch takes the general path).
-        h, pos_t, neg_t = ops.checked_ids(self.n_entities, h, pos_t, neg_t)     # (out-of-range ids never reach a kernel)
+        h, pos_t, neg_t = ops.checked_ids(self.id_space, h, pos_t, neg_t)     # (out-of-range ids never reach a kernel)
         (r,) = ops.checked_ids(self.n_relations, r, what="relation")
         check, k = None, int(self.pre_training_neg_rate)
         if self.scoring == "transr" and self.group_reuse and k >= self.group_reuse_min_rate:
@@ -570,7 +565,7 @@ class LiteralKG(nn.Module):
 
     # ------------------------------------------------------------------ f1 heads
     def calc_score(self, head_ids, tail_ids):
-        head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
+        head_ids, tail_ids = ops.checked_ids(self.id_space, head_ids, tail_ids)
         emb, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
         self._raise_bad_ids()
         return ops.gemm(ops.gather_rows(emb.detach(), head_ids), ops.gather_rows(emb.detach(), tail_ids),
@@ -596,7 +591,7 @@ class LiteralKG(nn.Module):
         """mode='mlp' (model.py:506-519): sigmoid(fc3(bn2(relu(fc2(bn1(relu(fc1([e_h | e_t])))))))) ."""
         if not hasattr(self, "fc1"):
             raise AttributeError("call initialize_MLP() first (model.py:499)")
-        head_ids, tail_ids = ops.checked_ids(self.n_entities, head_ids, tail_ids)
+        head_ids, tail_ids = ops.checked_ids(self.id_space, head_ids, tail_ids)
         self.gat_embed, (head_ids, tail_ids) = self._embeddings_and_ids(head_ids, tail_ids)
         self._raise_bad_ids()
         eh, et = ops.gather_rows_pair(self.gat_embed, head_ids, tail_ids, self._table_grad_stays_inside())
@@ -628,7 +623,7 @@ class LiteralKG(nn.Module):
 
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
         """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
-        head_ids, tail_pos_ids, tail_neg_ids = ops.checked_ids(self.n_entities, head_ids, tail_pos_ids, tail_neg_ids)
+        head_ids, tail_pos_ids, tail_neg_ids = ops.checked_ids(self.id_space, head_ids, tail_pos_ids, tail_neg_ids)
         self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
             head_ids, tail_pos_ids, tail_neg_ids)
         self._raise_bad_ids()

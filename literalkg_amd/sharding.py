@@ -224,13 +224,13 @@ class FeatureShardedAggregation:
         if (slab is None) == (block_in is None):
             raise ValueError("exchange_aggregate: exactly one of slab / block_in")
         src = slab if slab is not None else block_in
-        dev, dtype = src.device, src.dtype
+        dev, dtype, dg = src.device, src.dtype, int(src.shape[-1])     # (any width: the structure's parts do not depend on it)
         whole = _Whole(g, transposed)
         if block_in is not None and G > 1:
-            if tuple(block_in.shape) != (G, self.my_rows, self.dg):
-                raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected {(G, self.my_rows, self.dg)}")
+            if tuple(block_in.shape) != (G, self.my_rows, dg) or not block_in.is_contiguous():
+                raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected a contiguous {(G, self.my_rows, dg)}")
             batches, parts, vals = self.parts(transposed, n_batches)
-            slab = torch.empty((g.n, self.dg), dtype=dtype, device=dev)
+            slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
             slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # offset 0: no transfer
             staged = self._staged(block_in)
             queued = []
@@ -257,7 +257,7 @@ class FeatureShardedAggregation:
             vals = [self.val_t if transposed else self.val]
             queued = [([], [])]
         if side_slab is None:
-            side_slab = torch.empty((g.n, self.dg), dtype=dtype, device=dev)
+            side_slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
         live = [b for b, p in enumerate(parts) if p.nnz > 0] or [0]
         first = True
 
@@ -288,7 +288,7 @@ class FeatureShardedAggregation:
             return side_slab
         if G == 1:
             if out is None:
-                out = torch.empty((1, self.my_rows, self.dg), dtype=dtype, device=dev)
+                out = torch.empty((1, self.my_rows, dg), dtype=dtype, device=dev)
             out[0].copy_(side_slab)
         return side_slab, out
 
@@ -307,8 +307,9 @@ class FeatureShardedAggregation:
         r, G = self.rank, self.world
         if pieces is None:
             pieces = 4
+        dg = int(slab.shape[1])
         if out is None:
-            out = torch.empty((G, self.my_rows, self.dg), dtype=slab.dtype, device=slab.device)
+            out = torch.empty((G, self.my_rows, dg), dtype=slab.dtype, device=slab.device)
         staged = self._staged(slab)
 
         def piece(lo, hi, p):      # p-th of `pieces` sub-ranges of [lo, hi)
@@ -345,10 +346,10 @@ class FeatureShardedAggregation:
                     if hi > lo:
                         snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
                         ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
-                        self.bytes_sent += (hi - lo) * self.dg * side_slab.element_size()
+                        self.bytes_sent += (hi - lo) * dg * side_slab.element_size()
                     if rhi > rlo:
                         if staged:
-                            rcv = torch.empty((rhi - rlo, self.dg), dtype=out.dtype)
+                            rcv = torch.empty((rhi - rlo, dg), dtype=out.dtype)
                             host.append((rcv, i, rlo, rhi))
                         else:
                             rcv = out[i, rlo:rhi]

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from oracle import literalkg_oracle as O
 
 
-def spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, add_self=None):
+def spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, add_self=None, add2=None):
     rp = rowptr.long()
     lo, hi = int(rp[0]), int(rp[-1])
     rows = torch.repeat_interleave(torch.arange(n_rows), rp[1:] - rp[:-1])
@@ -17,6 +17,8 @@ def spmm(rowptr, col, val, x, n_rows, out=None, x_row_offset=0, long_rows=None, 
     res.index_add_(0, rows, val[lo:hi, None] * x[col[lo:hi].long() - x_row_offset])
     if add_self is not None:
         res = res + add_self
+    if add2 is not None:
+        res = res + add2
     if out is not None:
         out.copy_(res)
         return out
@@ -55,11 +57,39 @@ class CpuKernels:
         return out
 
     @staticmethod
-    def scatter_add_rows_range(rows, ids, lo, hi, like):
-        mine = (ids >= lo) & (ids < hi)
-        out = torch.zeros(like.shape, dtype=like.dtype)
-        out.index_add_(0, ids[mine] - lo, rows[mine])
-        return out
+    def gather_rows(table, ids):
+        return table.detach()[ids.long()]
+
+    # ---- row sets.  The HIP path carries them as tags from the loss down; plain autograd carries none, so the stand-in
+    # reads them off the data (a row is listed when it holds a non-zero): the same exchange protocol runs on them.
+    @staticmethod
+    def row_set(grad, force=False):
+        ids = torch.nonzero((grad != 0).any(dim=1)).flatten()
+        if not force and ids.numel() * 8 > grad.shape[0]:
+            return None
+        return ids
+
+    @staticmethod
+    def rows_table(n, d, device, id_lists, row_lists, pool):
+        t = torch.zeros((n, d), dtype=torch.float32)
+        for ids, rows in zip(id_lists, row_lists):
+            ok = (ids >= 0) & (ids < n)
+            t.index_add_(0, ids[ok], rows[ok])
+        return t
+
+    @staticmethod
+    def frontier_messages(rowptr, col, val, grad, rows, row0):
+        rp = rowptr.long()
+        d = grad.shape[1]
+        if rows.numel() == 0:
+            return rows, torch.zeros((0, d))
+        deg = rp[rows + 1] - rp[rows]
+        ent = torch.cat([torch.arange(int(rp[r]), int(rp[r + 1])) for r in rows.tolist()]) if int(deg.sum()) else torch.zeros(0, dtype=torch.long)
+        src = torch.repeat_interleave(rows - row0, deg)
+        tails, pos = torch.unique(col[ent].long(), return_inverse=True)
+        buf = torch.zeros((tails.numel(), d))
+        buf.index_add_(0, pos, val[ent, None] * grad[src])
+        return tails, buf
 
 
 def patch_ops():
@@ -73,16 +103,37 @@ def patch_ops():
         y = F.layer_norm(a, (z.shape[1],), gamma, beta, eps)
         return y, (F.normalize(y, p=2.0, dim=1, eps=norm_eps) if want_norm else None)
 
-    def assemble_cat(holder, parts):
+    def assemble_cat(holder, parts, pending=()):
         return torch.cat(list(parts), dim=1)
 
-    def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group=1):
+    def transr_loss(emb, relemb, trans_m, h, r, pos_t, neg_t, lam, keep=None, group=1, sparse_rows=False, slot0=None):
         cfg = O.default_cfg(kg_l2loss_lambda=lam)
         return O.triple_loss_transr({"relation_embed.weight": relemb, "gat_trans_M": trans_m}, cfg, emb, h, r, pos_t, neg_t)
 
-    def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None):
+    def transe_loss(emb, relemb, h, r, pos_t, neg_t, lam, keep=None, sparse_rows=False):
         cfg = O.default_cfg(kg_l2loss_lambda=lam)
         return O.triple_loss_transe({"relation_embed.weight": relemb}, cfg, emb, h, r, pos_t, neg_t)
+
+    def dot_loss(emb, h, pos_t, neg_t, lam, sparse_rows=False):
+        cfg = O.default_cfg(fine_tuning_l2loss_lambda=lam)
+        return O.prediction_loss(cfg, emb, h, pos_t, neg_t)
+
+    class GroupedCheck:
+        def __init__(self, h, r, pos_t, k):
+            self.answer = is_grouped_batch(h, r, pos_t, k)
+
+        def result(self):
+            return self.answer
+
+    def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, out=None, bias=None):
+        res = alpha * ((a.t() if trans_a else a) @ (b.t() if trans_b else b))
+        return res + bias if bias is not None else res
+
+    def gather_rows_pair(table, ids_a, ids_b, sparse_rows=False):
+        return table[ids_a.long()], table[ids_b.long()]
+
+    def relu_batchnorm(z, bn):
+        return bn(F.relu(z))
 
     def is_grouped_batch(h, r, pos_t, k):
         b = h.numel()
@@ -94,7 +145,13 @@ def patch_ops():
         z = torch.sigmoid(zpre)
         return (1 - z) * x + z * torch.tanh(gpre)
 
+    def bi_mix(ego, side, h0p=None, alpha=0.0):
+        if h0p is None:
+            return ego + side, ego * side
+        return (1 - alpha) * (ego + side) + alpha * h0p, (1 - alpha) * (ego * side) + alpha * h0p
+
     repl = dict(
+        bi_mix=bi_mix, stacked_linear=lambda x, ws, bs: [F.linear(x, w, b) for w, b in zip(ws, bs)],
         linear=lambda x, w, b=None: F.linear(x, w, b),
         multi_linear=lambda xs, ws, b=None: sum(F.linear(x, w) for x, w in zip(xs, ws)) + (b if b is not None else 0),
         matmul=lambda a, b: a @ b,
@@ -103,7 +160,11 @@ def patch_ops():
         leaky_relu=lambda a, slope=ops.LEAKY_SLOPE: F.leaky_relu(a, slope),
         leaky_relu_sum=lambda a, b, slope=ops.LEAKY_SLOPE: F.leaky_relu(a, slope) + F.leaky_relu(b, slope),
         act_layernorm=act_layernorm, assemble_cat=assemble_cat, transr_loss=transr_loss, transe_loss=transe_loss,
-        is_grouped_batch=is_grouped_batch, gate_blend=gate_blend,
+        is_grouped_batch=is_grouped_batch, gate_blend=gate_blend, dot_loss=dot_loss, GroupedCheck=GroupedCheck, gemm=gemm,
+        gather_rows_pair=gather_rows_pair, relu_batchnorm=relu_batchnorm,
+        gather_rows=lambda table, ids: table[ids.long()],
+        checked_ids=lambda n_rows, *id_lists, what="entity": [i.long() for i in id_lists],     # (bounds: the HIP path's job)
+        check_deferred_errors=lambda: None,
     )
     for k, v in repl.items():
         setattr(ops, k, v)
