@@ -543,7 +543,9 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
                                               long_rows, n_long, long_thresh, n_slabs, slab_cols, ex, s)  \
                : launch<V, LPE, CPL, U, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, \
                                                long_rows, n_long, long_thresh, n_slabs, slab_cols, ex, s)
-    if (nchunk <= 8)   // rows of <= 32 floats: 8 rows per wave (see spmm_csr_grouped_kernel)
+    // rows of <= 32 floats: 8 rows per wave (see spmm_csr_grouped_kernel); a row-sparse x -- the long rows behind
+    // spmm_flagged4_kernel -- stays on the wave-per-row kernel's flagged form
+    if (nchunk <= 8 && !ex.x_rows)
         return (nchunk == 8) ? launch_grouped<V, 8, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                             ld_self, long_rows, n_long, long_thresh, ex, s)
                              : launch_grouped<V, 8, 8, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
@@ -589,8 +591,9 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
         return LKG_ERR_HIP;
     }
-    LKG_REQUIRE(!out_rows || (x_rows && vec && !rowmax_out && d > 32),
-                "lkg_spmm_csr_fused_f32: out_rows needs x_rows, the 16-byte path (d %% 4 == 0, aligned rows), d > 32 and no rowmax_out");
+    LKG_REQUIRE(!out_rows || (x_rows && vec && !rowmax_out && !copy_dst && d <= 1024),
+                "lkg_spmm_csr_fused_f32: out_rows needs x_rows, the 16-byte path (d %% 4 == 0, aligned rows, d <= 1024), no row "
+                "copy and no rowmax_out");
     if (out_rows && hipMemsetAsync(out_rows, 0, n_rows, s) != hipSuccess) {
         lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
         return LKG_ERR_HIP;

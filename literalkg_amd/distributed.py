@@ -414,7 +414,8 @@ class _Aggregate(Function):
             counts = torch.cat([(at[1:] - at[:-1]).cpu(), torch.tensor([rows.numel()])])
         cdev = dev if dist.get_backend(att.group) != "gloo" else torch.device("cpu")
         every = _all_gather(counts.to(cdev), p.world, att.group, "frontier_counts").view(p.world, p.world + 1).cpu()
-        small = att.sparse_backward == "always" or int(every[:, :p.world].sum() + every[:, p.world].sum()) <= p.n_pad // 8
+        # (frontier rows + flagged rows over all ranks against the table the dense exchange would move: N_pad rows per rank)
+        small = att.sparse_backward == "always" or int(every[:, :p.world].sum() + every[:, p.world].sum()) <= p.n_pad // 2
         if bool((every >= 0).all()) and small:
             send = [int(c) for c in every[p.rank, :p.world]]
             recv = [int(c) for c in every[:, p.rank]]

@@ -158,13 +158,18 @@ class Aggregator(nn.Module):
         self.last_normalized = yn
         return y
 
+    def narrows(self) -> bool:
+        """A gcn layer of at most half its input's width (the reference's default 300 -> 32): it projects first and aggregates
+        out_dim columns (forward below)."""
+        return self.aggregator_type == "gcn" and not self.use_residual and 2 * self.out_dim <= self.in_dim
+
     def forward(self, ego_embeddings, A_in: AttentionCSR, all_layers, lamda, alpha, l):
         ego = ego_embeddings
         h0 = all_layers[0]
         kind = self.aggregator_type
         if kind == "gcn":   # ego + side comes out of the SpMM directly
             att = getattr(A_in, "att", A_in)         # (layer 1 arrives wrapped: _KeepingAttention)
-            if not self.use_residual and 2 * self.out_dim <= self.in_dim and isinstance(att, AttentionCSR):
+            if self.narrows() and isinstance(att, AttentionCSR):
                 # a layer that narrows (the reference's default: 300 -> 32): (ego + A ego) W^T + b = p + A p + b with
                 # p = ego W^T -- the aggregation gathers out_dim columns per entry instead of in_dim, forward and backward.
                 # Same sums in another order (fp32 rounding only); the bias rides in the SpMM's epilogue.
@@ -357,6 +362,12 @@ class LiteralKG(nn.Module):
                                              [layer.linear_h0.bias for layer in res_layers])
             for layer, proj in zip(res_layers, projections):
                 layer.h0_projection = proj        # (cleared layer by layer below; all of them if a layer raises)
+        if (self.aggregator_layers and self.aggregator_layers[0].narrows() and cur is not self.entity_embed.weight
+                and isinstance(att, AttentionCSR)):
+            # the gate's output has two consumers here -- column slot 0 of the concatenated table and the first layer's Linear
+            # (a narrowing layer projects before it aggregates) -- whose gradients are both zero outside a few rows in a
+            # one-layer model: joined by ops.fanout their sum stays row-sparse and the gate's backward runs on those rows
+            kept[0], cur = ops.fanout(cur)
         for idx, layer in enumerate(self.aggregator_layers):
             layer.norm_out = cb.slot(idx + 1)
             layer.want_output = idx + 1 < len(self.aggregator_layers)     # (the last layer's y is read by nobody)

@@ -666,7 +666,7 @@ class _Aggregate(Function):
         rows = _flags(rs) if rows_worth_compacting(rs, g.n) else None      # (a dense-ish row set: the plain kernel is faster)
         grad = _f32_rows(grad)
         d = grad.shape[1]
-        if (rows_worth_compacting(rs, g.n) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0 and d > 32
+        if (rows_worth_compacting(rs, g.n) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0 and d <= 1024
                 and grad.data_ptr() % 16 == 0 and _ld(grad) % 4 == 0):
             # ... and the rows it reaches in turn (the gradient's frontier) are few as well: the result goes into a table kept
             # all-zero elsewhere, the kernel flags the rows it wrote, and the layer below works on those (one host sync: their
@@ -723,13 +723,68 @@ class _AggregateKeep(Function):
         rs = tagged_rows(g_side)
         rows = _flags(rs) if rows_worth_compacting(rs, g.n) else None
         g_side = _f32_rows(g_side)
+        rk = tagged_rows(g_kept)
+        d = g_side.shape[1]
+        if (rows is not None and (g_kept is None or rk is not None) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0
+                and d <= 1024 and g_side.data_ptr() % 16 == 0 and _ld(g_side) % 4 == 0
+                and (g_kept is None or (g_kept.data_ptr() % 16 == 0 and _ld(g_kept) % 4 == 0))):
+            # both gradients are zero outside a few rows (a one-layer model behind a gate: the loss's rows and what one
+            # transpose SpMM reaches from them): the sum goes into a table kept all-zero elsewhere, the kernel flags the rows
+            # it wrote, and the gate's backward works on those
+            ent = _RowScratch.acquire(g.n, d, g_side.device, "g_agg_keep")
+            out = ent.buf.view(ent.buf.shape)
+            reached = torch.empty(g.n, dtype=torch.uint8, device=g_side.device)
+            ent.unknown = True
+            spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, out=out, long_rows=g.long_rows(True),
+                     add_self=g_side if ctx.plus_self else None, add2=g_kept, add2_rows=_flags(rk), x_rows=rows, self_rows=rows,
+                     out_rows=reached)
+            ids = torch.nonzero(reached).flatten()
+            ent.dirty.append(ids)
+            ent.unknown = False
+            return tag_rows(out, RowSet(reached, [ids], unique=True)), None, None, None, None, None
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
                         add_self=g_side if ctx.plus_self else None, add2=g_kept,
-                        add2_rows=_flags(tagged_rows(g_kept)), x_rows=rows, self_rows=rows), None, None, None, None, None
+                        add2_rows=_flags(rk), x_rows=rows, self_rows=rows), None, None, None, None, None
 
 
 def aggregate_keep(ego, g: KGStructure, val, val_t, plus_self: bool = False, keep_dst: Optional[torch.Tensor] = None):
     return _AggregateKeep.apply(ego, g, val, val_t, plus_self, keep_dst)
+
+
+class _Fanout(Function):
+    """One tensor, two consumers, and a backward that keeps what autograd's own sum of the two gradients loses: when both
+    are zero outside a few rows (the loss's rows of column slot 0 of the concatenated table, and the rows a layer's backward
+    reached) the sum is built on the union of those rows, in a table kept all-zero elsewhere that says which rows they are --
+    autograd would add two N x D tables (a pass over both) and hand the layer below a dense, untagged one."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        ra, rb = tagged_rows(ga), tagged_rows(gb)
+        n, d = ga.shape
+        if ra is not None and rb is not None and rows_worth_compacting(ra, n) and rows_worth_compacting(rb, n):
+            flags = ra.flags.clone()
+            rows = union_rows(RowSet(flags, ra.id_lists), rb)
+            if rows_worth_compacting(rows, n):
+                out = zero_table_for(rows, n, d, ga.device, "g_fanout")
+                for g_, r_ in ((ga, ra), (gb, rb)):
+                    ids = r_.compact_ids()
+                    part = gather_rows_range(g_, ids, 0, n)
+                    N.call("lkg_scatter_add_rows_range_f32", ids.numel(), d, N.ptr(part), d, N.ptr(ids), 0, n, N.ptr(out), _ld(out),
+                           _stream())
+                return out
+        return _elt(0, ga, gb, 1.0, 1.0)
+
+
+def fanout(x: torch.Tensor):
+    """(x, x) for two consumers whose gradients may both be row-sparse (see _Fanout)."""
+    return _Fanout.apply(x)
 
 
 # ----------------------------------------------------------------------------- dense layers on the MFMA GEMM
@@ -1262,8 +1317,11 @@ class _FusedGate(Function):
         sv = ctx.saved_tensors
         x, g, z = sv[0], sv[1], sv[2]
         lits, wgs, wzs = sv[3:3 + nl], sv[3 + nl:4 + 2 * nl], sv[4 + 2 * nl:]
+        rows = tagged_rows(go)
         go = _f32_rows(go)
         n, d = x.shape
+        if rows_worth_compacting(rows, n):
+            return _FusedGate._backward_on_rows(ctx, go, rows, x, g, z, lits, wgs, wzs)
         gx = torch.empty((n, d), dtype=torch.float32, device=x.device)
         gpz = torch.empty((n, 2 * d), dtype=torch.float32, device=x.device)      # [g_gpre | g_zpre]
         ggp, gzp = gpz[:, :d], gpz[:, d:]
@@ -1320,6 +1378,45 @@ class _FusedGate(Function):
         gb_g = gb[:d] if (gb is not None and need[1]) else None
         gb_z = gb[d:] if (gb is not None and need[2]) else None
         return (None, gb_g, gb_z, None, None, g_x, *([None] * nl), *g_wg, *g_wz)
+
+
+def _fused_gate_backward_on_rows(ctx, go, rows: RowSet, x, g, z, lits, wgs, wzs):
+    """go is zero outside ``rows`` (a one-layer model: the loss's rows and the rows one transpose SpMM reaches from them, a few
+    percent of the entities): every product of the gate's backward is the same product over the listed rows -- x, tanh(g),
+    sigmoid(z), the literals and go gathered once -- and the gradient of x is their scatter into a table kept all-zero elsewhere.
+    Only zero addends are dropped."""
+    nl = ctx.n_lit
+    n, d = x.shape
+    need = ctx.needs_input_grad           # (out, bg, bz, n_lit, grad_mode, x, lits..., wgs..., wzs...)
+    ids = rows.compact_ids()              # every row once, -1 padding (gathers as zeros: go = 0 there, so every gradient is 0)
+    nc = ids.numel()
+    goc = gather_rows_range(go, ids, 0, n)
+    xc, gc, zc = (gather_rows_range(t_, ids, 0, n) for t_ in (x, g, z))
+    gxc = torch.empty((nc, d), dtype=torch.float32, device=x.device)
+    gpz = torch.empty((nc, 2 * d), dtype=torch.float32, device=x.device)      # [g_gpre | g_zpre]
+    ggp, gzp = gpz[:, :d], gpz[:, d:]
+    N.call("lkg_gate_blend_bwd_f32", nc, d, N.ptr(xc), d, N.ptr(gc), d, N.ptr(zc), d, N.ptr(goc), d, N.ptr(gxc), d, N.ptr(ggp),
+           _ld(ggp), N.ptr(gzp), _ld(gzp), 1, None, _stream())
+    g_x = None
+    if need[5]:
+        gemm(ggp, wgs[0], beta=1.0, out=gxc)
+        gemm(gzp, wzs[0], beta=1.0, out=gxc)
+        g_x = zero_table_for(rows, n, d, x.device, "g_gate_x")
+        N.call("lkg_scatter_add_rows_range_f32", nc, d, N.ptr(gxc), d, N.ptr(ids), 0, n, N.ptr(g_x), _ld(g_x), _stream())
+    base = 6 + nl
+    want = [need[base + i] or need[base + nl + 1 + i] for i in range(nl + 1)]
+    want_bias = ctx.has_bias and (need[1] or need[2])
+    panels = [xc] + [gather_rows_range(_f32_rows(l), ids, 0, n) if want[i + 1] else None for i, l in enumerate(lits)]
+    gws = [gemm(gpz, panels[i], trans_a=True) if want[i] else None for i in range(nl + 1)]
+    gb = colsum(gpz) if want_bias else None
+    g_wg = [gws[i][:d] if need[base + i] else None for i in range(nl + 1)]
+    g_wz = [gws[i][d:] if need[base + nl + 1 + i] else None for i in range(nl + 1)]
+    gb_g = gb[:d] if (gb is not None and need[1]) else None
+    gb_z = gb[d:] if (gb is not None and need[2]) else None
+    return (None, gb_g, gb_z, None, None, g_x, *([None] * nl), *g_wg, *g_wz)
+
+
+_FusedGate._backward_on_rows = staticmethod(_fused_gate_backward_on_rows)
 
 
 def fused_gate(x, lits: Sequence[torch.Tensor], wg_panels: Sequence[torch.Tensor], wz_panels: Sequence[torch.Tensor],

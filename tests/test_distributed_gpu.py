@@ -84,8 +84,8 @@ def _frontier_worker(rank, world, port, scheme, q):
         import literalkg_amd as L
         from literalkg_amd import distributed as D, io
         from literalkg_amd.synth import make_batch, make_kg
-        n, dim = 40_000, 64
-        h, t, r = make_kg(n, 300_000, seed=3)
+        n, dim = 100_000, 64
+        h, t, r = make_kg(n, 400_000, seed=3)
         cfg = SimpleNamespace(use_pretrain=0, device=dev, embed_dim=dim, relation_dim=dim, scale_gat_dim=None,
                               use_residual=False, alpha=0.1, lamda=0.5, aggregation_type="gcn", n_conv_layers=2,
                               conv_dim=dim, mess_dropout=0.0, kg_l2loss_lambda=1e-5, fine_tuning_l2loss_lambda=1e-5,
@@ -125,7 +125,7 @@ def _frontier_worker(rank, world, port, scheme, q):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("scheme", ["rows", "features"])
 def test_frontier_exchange_equals_the_dense_exchange_on_the_kernels(gpu_device, scheme):
-    """40 k entities, 2 layers, 2 ranks on the one GPU: the row sets the loss leaves on its gradient reach both
+    """100 k entities, 2 layers, 2 ranks on the one GPU: the row sets the loss leaves on its gradient reach both
     aggregations' backward (tags through act_ln / Linear on the real kernels), which then exchange frontier rows; loss and
     every gradient equal the dense exchange's."""
     import __graft_entry__ as ge

@@ -1960,7 +1960,8 @@ def test_gradient_frontier_two_layers_equals_the_dense_backward(L, ops, O, gpu_d
 
 
 @pytest.mark.parametrize("variant", ["dropout_train", "gin", "scale_gat_dim", "gatemul_3layers", "transe", "fine_tuning",
-                                     "sage_res_dropout", "gatenum_scale_dropout", "mlp_head"])
+                                     "sage_res_dropout", "gatenum_scale_dropout", "mlp_head", "one_layer_gate_narrow",
+                                     "one_layer_gate_wide", "narrow_two_layers"])
 def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, variant):
     """The row-sparse backward (kept-zero tables, row sets, gradient frontier, Linear backward on listed rows) is active
     from 16 384 entity rows on -- sizes the reference-fixture tests do not reach.  Here every model family runs at 40 k
@@ -1992,6 +1993,16 @@ def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, varia
         over.update(use_num_lit=True, scale_gat_dim=80, mess_dropout=0.1); train = True
     elif variant == "mlp_head":
         over.update(scale_gat_dim=48); mode = "mlp"
+    elif variant == "one_layer_gate_narrow":
+        # argument_finetuning.py's shape: ONE narrowing gcn layer behind GateMul, linear_gat on top, the fine-tuning head --
+        # the 32-wide transpose SpMM follows the gradient's frontier, the gate's two consumers are joined row-sparsely
+        # (ops.fanout) and the gate's backward runs on the listed rows
+        over.update(n_conv_layers=1, conv_dim=32, use_num_lit=True, use_txt_lit=True, txt_lit_dim=40, scale_gat_dim=64)
+        mode = "fine_tuning"
+    elif variant == "one_layer_gate_wide":
+        over.update(n_conv_layers=1, use_num_lit=True, use_txt_lit=True, txt_lit_dim=40)       # (the SpMM that also keeps slot 0)
+    elif variant == "narrow_two_layers":
+        over.update(conv_dim=32)                      # 64 -> 32 -> 32: the frontier through 32-wide tables
     cfg = O.default_cfg(**over)
     torch.manual_seed(5)
     num = torch.rand(n, 2) if cfg.use_num_lit else None
@@ -2020,10 +2031,18 @@ def test_row_sparse_machinery_across_model_variants(L, ops, O, gpu_device, varia
         return out, {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
 
     try:
-        (l1, got), (l0, want) = grads(True), grads(False)
+        l1, got = grads(True)
+        pools = {k[3] for k in ops._RowScratch._tables}
+        l0, want = grads(False)
     finally:
         del m._table_grad_stays_inside
         ops._RowScratch._tables.clear()
+    if variant == "one_layer_gate_narrow":
+        assert {"g_agg", "g_fanout", "g_gate_x"} <= pools, pools
+    elif variant == "one_layer_gate_wide":
+        assert {"g_agg_keep", "g_gate_x"} <= pools, pools
+    elif variant == "narrow_two_layers":
+        assert "g_agg" in pools, pools
     assert l1 == l0 and all(np.isfinite(l1)), (l1, l0)
     assert got.keys() == want.keys() and len(want) >= 4
     for k in want:
