@@ -110,6 +110,12 @@ int lkg_triples_dedup(int64_t n, const int64_t *h, const int64_t *r, const int64
 int lkg_laplacian_f32(int64_t n_entities, int64_t n_raw, int64_t nnz, const int32_t *rowptr,
                       const int32_t *col, const int32_t *eptr, const int32_t *rel, int32_t kind,
                       float *val_out);
+/* The same on the DEVICE, over the arrays lkg_csr_build_device left in HBM (all pointers device memory): n_rel = number of
+ * relations (max relation id + 1), deg_workspace int32[n_entities * n_rel] scratch.  Same f64 arithmetic as the host form:
+ * the values agree bit for bit.                                                                                      */
+int lkg_laplacian_device_f32(int64_t n_entities, int64_t nnz, int32_t n_rel, const int32_t *rowptr, const int32_t *col,
+                             const int32_t *eptr, const int32_t *rel, int32_t kind, int32_t *deg_workspace,
+                             float *val_out, void *stream);
 
 /* ---------------------------------------------------------------- device --
  * K3/K4  neighbour aggregation  out[i,:] = sum_{j in row i} val[j] * x[col[j],:]

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "lkg_triples_read": [C.c_char_p, i64, vp, vp, vp, vp],
     "lkg_triples_dedup": [i64, vp, vp, vp, vp, vp],
     "lkg_laplacian_f32": [i64, i64, i64, vp, vp, vp, vp, i32, vp],
+    "lkg_laplacian_device_f32": [i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "lkg_spmm_csr_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp],
     "lkg_spmm_csr_fused_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp,
                                vp, vp, vp, i32, i32, vp],

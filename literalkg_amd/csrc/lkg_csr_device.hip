@@ -408,6 +408,71 @@ extern "C" int lkg_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t 
     return LKG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The loader's initial attention on the device (dataloader.py:449-495): A_in = sum_r norm(A_r) over the structure the
+// device build left in HBM -- the host form (lkg_laplacian_f32) walks numpy mirrors of it.  Two passes, one wave per head
+// row: out-degree of every (entity, relation) pair into deg[n x n_rel]; then every stored entry sums its raw edges'
+// 1 / d_r(h)  (random-walk)  or  d_r(h)^-1/2 d_r(t)^-1/2  (symmetric, the ROW sums on both sides as the reference) in f64,
+// the arithmetic (and so the bits) of the host form.
+namespace {
+__global__ __launch_bounds__(256) void lap_degree_kernel(long n, int n_rel, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ eptr, const int *__restrict__ rel,
+                                                          int *__restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int j0 = rowptr[i], j1 = rowptr[i + 1];
+    if (j0 == j1) return;
+    const int e0 = eptr ? eptr[j0] : j0, e1 = eptr ? eptr[j1] : j1;       // the row's raw edges are contiguous
+    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(deg + i * n_rel + rel[e], 1);
+}
+
+__global__ __launch_bounds__(256) void lap_values_kernel(long n, int n_rel, int kind, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ col, const int *__restrict__ eptr,
+                                                          const int *__restrict__ rel, const int *__restrict__ deg,
+                                                          float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int j0 = rowptr[i], j1 = rowptr[i + 1];
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const int e0 = eptr ? eptr[j] : j, e1 = eptr ? eptr[j + 1] : j + 1;
+        double acc = 0.0;
+        for (int e = e0; e < e1; ++e) {
+            const double dh = deg[i * n_rel + rel[e]];
+            if (kind == 0) {
+                acc += 1.0 / dh;
+            } else {
+                const double dt = deg[(long)col[j] * n_rel + rel[e]];
+                if (dt > 0) acc += 1.0 / sqrt(dh) / sqrt(dt);
+            }
+        }
+        val[j] = (float)acc;
+    }
+}
+}  // namespace
+
+extern "C" int lkg_laplacian_device_f32(int64_t n_entities, int64_t nnz, int32_t n_rel, const int32_t *rowptr,
+                                        const int32_t *col, const int32_t *eptr, const int32_t *rel, int32_t kind,
+                                        int32_t *deg_workspace, float *val_out, void *stream) {
+    LKG_REQUIRE(n_entities >= 0 && n_entities < INT32_MAX && nnz >= 0 && n_rel > 0 && (kind == 0 || kind == 1),
+                "lkg_laplacian_device_f32: bad arguments");
+    if (nnz == 0 || n_entities == 0) return LKG_OK;
+    LKG_REQUIRE(rowptr && col && rel && deg_workspace && val_out, "lkg_laplacian_device_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(deg_workspace, 0, sizeof(int32_t) * (size_t)n_entities * n_rel, s) != hipSuccess) {
+        lkg_set_error("lkg_laplacian_device_f32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    const unsigned blocks = (unsigned)((n_entities + 3) / 4);
+    hipLaunchKernelGGL(lap_degree_kernel, dim3(blocks), dim3(256), 0, s, (long)n_entities, n_rel, rowptr, eptr, rel,
+                       deg_workspace);
+    hipLaunchKernelGGL(lap_values_kernel, dim3(blocks), dim3(256), 0, s, (long)n_entities, n_rel, kind, rowptr, col, eptr,
+                       rel, deg_workspace, val_out);
+    LKG_CHECK_LAUNCH("lkg_laplacian_device_f32");
+    return LKG_OK;
+}
+
 // lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
 // attributes is such a use (no launch).
 int lkg_internal_preload_csr_device() {

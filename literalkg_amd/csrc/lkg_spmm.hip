@@ -11,6 +11,8 @@
 //     wave is split into 64/LPE sub-groups that gather different edges at once and are summed
 //     with xor-shuffles at the end, so every lane always carries a 16-byte load;
 //   * U edges are kept in flight per sub-group (unrolled, loads issued before the FMAs).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -533,6 +535,11 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
     return LKG_OK;
 }
 
+inline int grouped_max_chunks() {        // (read per call: the micro-benchmark switches it inside one process)
+    const char *e = getenv("LKG_SPMM_GROUPED_CHUNKS");
+    return e ? atoi(e) : 8;
+}
+
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
              int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
@@ -550,6 +557,15 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
                                                             ld_self, long_rows, n_long, long_thresh, ex, s)
                              : launch_grouped<V, 8, 8, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                              ld_self, long_rows, n_long, long_thresh, ex, s);
+    if constexpr (std::is_same<V, float4>::value) {
+        // experiment (LKG_SPMM_GROUPED_CHUNKS=16|32): several rows per wave for 64- / 128-column rows too
+        if (!ex.x_rows && n_slabs == 1 && nchunk == 16 && grouped_max_chunks() >= 16)
+            return launch_grouped<V, 16, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
+                                                  n_long, long_thresh, ex, s);
+        if (!ex.x_rows && n_slabs == 1 && nchunk == 32 && grouped_max_chunks() >= 32)
+            return launch_grouped<V, 32, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
+                                                  n_long, long_thresh, ex, s);
+    }
     if (nchunk <= 16) LKG_GO(16, 1, 4);
     if (nchunk <= 32) LKG_GO(32, 1, 4);
     if (nchunk <= 64) LKG_GO(64, 1, 4);
@@ -640,7 +656,8 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     }
     // (over a row-sparse x almost nothing is gathered: one pass over the entry stream per 256 columns, not per 128)
     const int block_cols = (vec && !x_rows) ? 128 : 256;
-    if (d > block_cols && d % block_cols == 0)     // equal slabs: one launch, slab-major workgroup order
+    const bool grouped_slabs = vec && !x_rows && block_cols / 4 <= grouped_max_chunks();   // (experiment: one launch per slab)
+    if (d > block_cols && d % block_cols == 0 && !grouped_slabs)     // equal slabs: one launch, slab-major workgroup order
         return vec ? dispatch<float4>(n_rows, block_cols / 4, rowptr, col, val, x, ldx, out, ldo, self, ld_self,
                                       long_rows, n_long, long_thresh, d / block_cols, block_cols, ex, s)
                    : dispatch<float>(n_rows, block_cols, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,

@@ -116,16 +116,13 @@ class HipKernels:
         for ids in id_lists:
             if ids.numel():
                 N.call("lkg_fill_rows_f32", ids.numel(), 0, N.ptr(ids), None, 0, 0.0, N.ptr(flags), 1, ops._stream())
-        if not ops._HAS_USE_COUNT:
-            t = torch.zeros((n, d), dtype=torch.float32, device=device)
-        else:
-            t = ops.zero_table_for(ops.RowSet(flags, id_lists), n, d, device, pool)
+        t = ops.zero_table_for(ops.RowSet(flags, id_lists), n, d, device, pool)
         for ids, rows in zip(id_lists, row_lists):
             if ids.numel():
                 rows = ops._f32_rows(rows)
                 N.call("lkg_scatter_add_rows_range_f32", ids.numel(), d, N.ptr(rows), ops._ld(rows), N.ptr(ids), 0, int(n),
                        N.ptr(t), ops._ld(t), ops._stream())
-        return t if ops._HAS_USE_COUNT else ops.tag_rows(t, ops.RowSet(flags, id_lists))
+        return t
 
     def frontier_messages(self, rowptr, col, val, grad, rows, row0: int):
         """A[rows, :]^T grad[rows - row0, :] as (tails, one summed row per tail): ``rows`` = sorted ids of the structure's

@@ -2,9 +2,14 @@
 
 Parameter names and shapes follow the reference's ``GateMul`` / ``Gate`` (gate.py:5-51) so that
 checkpoints interchange.  The arithmetic differs in structure: the reference concatenates
-``[x | num | txt]`` (an N x (D+302) copy) before ``g``; here ``g.weight`` is addressed as column
-panels and every panel is one accumulating MFMA GEMM, then a single fused blend kernel applies
-tanh / sigmoid / mix (K6).
+``[x | num | txt]`` (an N x (D+302) copy) before ``g`` and runs four Linears; here the whole gate is ONE
+launch from 16 384 rows on (``ops.fused_gate``): the ``g`` and ``z`` projections as one stacked tall GEMM
+whose K-panels are x and the literal tables as they lie in memory, tanh / sigmoid / blend in its epilogue,
+the result written straight into its column slot of the concatenated table; the backward is one blend
+kernel + one two-panel data-gradient product + one long-k product per wide panel -- or, when the incoming
+gradient is zero outside a few rows (one-layer models), the same products over those rows alone.  Below
+16 384 rows: one accumulating panel GEMM per input panel (``ops.multi_linear``) and the blend kernel
+(``ops.gate_blend``).
 """
 import torch
 import torch.nn as nn

@@ -64,6 +64,14 @@ class _Deferred:
     polls (or ``check_deferred_errors()``, which waits) raises -- the way an asynchronous device-side assert of the
     reference's ``gat_trans_M[r]`` would surface one call late."""
     pending = []
+    _lock = None
+
+    @classmethod
+    def _guard(cls):
+        if cls._lock is None:
+            import threading
+            cls._lock = threading.Lock()
+        return cls._lock
 
     @classmethod
     def watch(cls, counter: torch.Tensor, exc, message: str):
@@ -71,19 +79,24 @@ class _Deferred:
         host.copy_(counter, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        cls.pending.append((ev, host, exc, message))
+        with cls._guard():
+            cls.pending.append((ev, host, exc, message))
 
     @classmethod
     def poll(cls, wait: bool = False):
+        with cls._guard():                    # (replica threads share the list: each takes what is there and puts back the rest)
+            mine, cls.pending = cls.pending, []
         keep, err = [], None
-        for ev, host, exc, message in cls.pending:
+        for ev, host, exc, message in mine:
             if wait:
                 ev.synchronize()
             if not ev.query():
                 keep.append((ev, host, exc, message))
             elif int(host.sum()) != 0 and err is None:
                 err = exc(message.format(n=int(host.sum())))
-        cls.pending = keep
+        if keep:
+            with cls._guard():
+                cls.pending = keep + cls.pending
         if err is not None:
             raise err
 
@@ -388,23 +401,35 @@ _HAS_USE_COUNT = hasattr(torch._C, "_storage_Use_Count")
 
 
 def _storage_users(t: torch.Tensor) -> int:
-    """How many tensors / views share t's storage (a private torch hook; without it the kept-zero tables are not used)."""
+    """How many tensors / views share t's storage, or -1 when this torch build cannot tell (the counter torch's own
+    multiprocessing reductions read; without it a kept-zero table is never RE-used -- see _RowScratch.acquire)."""
+    if not _HAS_USE_COUNT:
+        return -1
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+import threading as _threading
 
 
 class _RowScratch:
     """The gradient a loss returns for the N x C entity table touches <= 3B of its rows, yet autograd wants it dense:
-    an N x C zero fill per step (2 GB at 1 M x 512) plus the consumers' reads of those zeros.  Here ONE table per shape
-    (and purpose) is kept all-zero BETWEEN steps: a backward resets the rows the previous one touched
+    an N x C zero fill per step (2 GB at 1 M x 512) plus the consumers' reads of those zeros.  Here ONE table per shape,
+    purpose AND STREAM is kept all-zero BETWEEN steps: a backward resets the rows the previous one touched
     (lkg_fill_rows_f32), scatters its own, and tags the result with the RowSet so that the aware consumers skip the zero
     rows: act_ln backward, the transpose SpMM, and -- for the LAST layer, whose only gradient is that table's slice --
-    the Linear's whole backward, which then works on the listed rows alone.  Only for tables whose gradient is consumed
-    inside the backward pass by this package's own Functions (the caller says so: ``sparse_rows``); as a second guard a
-    table is re-used only when no view of it is alive any more (storage use count back at its baseline), otherwise a
-    fresh one replaces it."""
+    the Linear's whole backward, which then works on the listed rows alone.
+
+    Ownership.  A table is handed out as a fresh view; it may be handed out AGAIN only when nothing but this registry
+    holds its storage any more -- no view of it alive in a graph, in a hook, as a parameter's .grad (autograd adopts a
+    gradient tensor it is given when it can).  That is read off the storage's use count; a torch build without that
+    counter never re-uses a table (every acquire allocates a fresh zero table: correct, one fill slower).  The registry is
+    keyed by (device, rows, columns, purpose, stream) -- two models training on two streams never share a table, whose
+    reset / scatter launches are ordered by ONE stream only -- and guarded by a lock (nn.DataParallel's replica threads,
+    main_pretraining.py:69-71, run their backward passes concurrently)."""
 
     _tables: dict = {}
-    MAX_TABLES = 8
+    _lock = _threading.Lock()
+    MAX_TABLES = 16
 
     def __init__(self, shape, device, with_flags: bool):
         self.buf = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
@@ -415,13 +440,15 @@ class _RowScratch:
 
     @classmethod
     def acquire(cls, n: int, c: int, device, pool: str = "loss") -> "_RowScratch":
-        key = (device, n, c, pool)
-        ent = cls._tables.pop(key, None)
-        if ent is None or _storage_users(ent.buf) != ent.users:
-            ent = _RowScratch((n, c), device, pool == "loss")
-        cls._tables[key] = ent                       # (most recently used last)
-        while len(cls._tables) > cls.MAX_TABLES:     # another model / shape: let the oldest table go
-            cls._tables.pop(next(iter(cls._tables)))
+        key = (device, n, c, pool, _stream())
+        with cls._lock:
+            ent = cls._tables.pop(key, None)
+        if ent is None or ent.users < 0 or _storage_users(ent.buf) != ent.users:
+            ent = _RowScratch((n, c), device, pool == "loss")     # (somebody still holds the old one: it is theirs now)
+        with cls._lock:
+            cls._tables[key] = ent                   # (most recently used last)
+            while len(cls._tables) > cls.MAX_TABLES:     # another model / shape / stream: let the oldest table go
+                cls._tables.pop(next(iter(cls._tables)))
         if ent.unknown:               # (only after an exception between a kernel's writes and their book-keeping)
             ent.buf.zero_()
             if ent.flags is not None:
@@ -447,7 +474,7 @@ class _RowScratch:
 
 def _loss_grad_table(emb: torch.Tensor, sparse_rows: bool, *id_lists: torch.Tensor) -> torch.Tensor:
     """The all-zero N x C table a loss backward scatters its rows ``id_lists`` (int64, contiguous) into."""
-    if not sparse_rows or not _HAS_USE_COUNT:
+    if not sparse_rows:
         return torch.zeros_like(emb, memory_format=torch.contiguous_format)
     ent = _RowScratch.acquire(emb.shape[0], emb.shape[1], emb.device)
     ent.mark(*id_lists)
@@ -1675,7 +1702,7 @@ class _GatherPair(Function):
     def backward(ctx, ga, gb):
         ids_a, ids_b = ctx.saved_tensors
         shape, device, sparse = ctx.meta
-        if sparse and _HAS_USE_COUNT:
+        if sparse:
             ent = _RowScratch.acquire(shape[0], shape[1], device)
             ent.mark(ids_a, ids_b)
             g_tab = ent.table(RowSet(ent.flags, [ids_a, ids_b]))
