@@ -535,6 +535,11 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
     return LKG_OK;
 }
 
+inline int spmm_u() {
+    const char *e = getenv("LKG_SPMM_U");
+    return e ? atoi(e) : 4;
+}
+
 inline int grouped_max_chunks() {        // (read per call: the micro-benchmark switches it inside one process)
     const char *e = getenv("LKG_SPMM_GROUPED_CHUNKS");
     return e ? atoi(e) : 8;
@@ -567,7 +572,11 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
                                                   n_long, long_thresh, ex, s);
     }
     if (nchunk <= 16) LKG_GO(16, 1, 4);
-    if (nchunk <= 32) LKG_GO(32, 1, 4);
+    if (nchunk <= 32) {
+        if (spmm_u() == 8) LKG_GO(32, 1, 8);      // (experiment LKG_SPMM_U=8 | 2: gathers in flight per half-wave)
+        if (spmm_u() == 2) LKG_GO(32, 1, 2);
+        LKG_GO(32, 1, 4);
+    }
     if (nchunk <= 64) LKG_GO(64, 1, 4);
     if (nchunk <= 128) LKG_GO(64, 2, 4);
     if (nchunk <= 192) LKG_GO(64, 3, 2);

@@ -171,6 +171,38 @@ REF_KG = "/root/reference/data/Test/pre_training_train.txt"
 
 
 @pytest.mark.skipif(not os.path.exists(REF_KG), reason="reference mount absent (GPU box): build-container check only")
+def test_triples_file_parsed_and_deduplicated_by_many_threads(native, tmp_path):
+    """Files beyond a few MB are parsed over line-aligned byte ranges by several threads and de-duplicated bucket by bucket
+    (lkg_triples_read / lkg_triples_dedup): same answer as pandas' drop_duplicates(keep='first') in file order
+    (dataloader.py:186-190), blank lines and a CRLF ending included; a malformed line anywhere is still an error."""
+    import pandas as pd
+    from literalkg_amd import io
+    rng = np.random.default_rng(1)
+    n = 800_000
+    h, r, t = rng.integers(0, 40_000, n), rng.integers(0, 8, n), rng.integers(0, 40_000, n)
+    dup = rng.integers(0, n, 60_000)
+    h[dup], r[dup], t[dup] = h[(dup * 7) % n], r[(dup * 7) % n], t[(dup * 7) % n]
+    df = pd.DataFrame({"h": h, "r": r, "t": t})
+    path = tmp_path / "kg_final.txt"
+    df.to_csv(path, sep=" ", header=False, index=False)
+    with open(path, "a") as f:
+        f.write("\n\n7 1 9\r\n")
+    assert os.path.getsize(path) > 8 << 20                    # (several parser threads)
+    hh, rr, tt = io.load_triples(str(path))
+    want = pd.concat([df, pd.DataFrame({"h": [7], "r": [1], "t": [9]})], ignore_index=True).drop_duplicates(keep="first")
+    assert len(want) < n and len(hh) == len(want)
+    assert np.array_equal(hh, want["h"].to_numpy()) and np.array_equal(rr, want["r"].to_numpy())
+    assert np.array_equal(tt, want["t"].to_numpy())
+    h2, r2, t2 = io.load_triples(str(path), drop_duplicates=False)
+    assert len(h2) == n + 1 and np.array_equal(h2[:n], h) and np.array_equal(t2[:n], t) and (h2[-1], r2[-1], t2[-1]) == (7, 1, 9)
+    with open(path, "r+") as f:                               # damage a line in the middle of the file
+        f.seek(os.path.getsize(path) // 2)
+        f.readline()
+        f.write("x")
+    with pytest.raises(native.LkgError, match="malformed"):
+        io.load_triples(str(path))
+
+
 def test_ingest_the_reference_kg_file(native):
     """The reference's only complete KG file: parse, drop duplicates and build A_in like its DataLoader
     (dataloader.py:186-190, 449-495), against pandas / the oracle's restatement."""

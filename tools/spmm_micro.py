@@ -67,6 +67,14 @@ for skew in ap_skews:
             print(f"{skew:8s} D={d} {name} rows-per-wave kernel for <= {gval} chunks: median {med:.3f} ms  min {mn:.3f} ms -> "
                   f"{by/med/1e6:.0f} GB/s ({by/med/1e6/8000:.3f} of 8 TB/s)")
         del os.environ["LKG_SPMM_GROUPED_CHUNKS"]
+    for uval in [v for v in os.environ.get("LKG_MICRO_U", "").split(",") if v]:
+        os.environ["LKG_SPMM_U"] = uval
+        for name, fn in [("fwd", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
+                         ("bwd", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out, long_rows=g.long_rows(True)))]:
+            med, mn = timeit(fn)
+            print(f"{skew:8s} D={d} {name} U={uval} gathers in flight per half-wave: median {med:.3f} ms  min {mn:.3f} ms -> "
+                  f"{by/med/1e6:.0f} GB/s ({by/med/1e6/8000:.3f} of 8 TB/s)")
+        del os.environ["LKG_SPMM_U"]
     # plain copy reference for this box: read+write 2 x table
     y = torch.empty_like(x)
     med, _ = timeit(lambda: y.copy_(x))
