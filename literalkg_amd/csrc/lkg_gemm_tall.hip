@@ -181,52 +181,46 @@ void gemm_tall_kernel(TallArgs g) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     constexpr int RING = 3;                        // raw A tiles (f32, as loaded) in flight
     float *raw_s = reinterpret_cast<float *>(smem + 2 * BUF);
+    // exponents / bias of the tile's rows and BN stacked columns: read in its epilogue without a global round trip
     int *ea_s = reinterpret_cast<int *>(raw_s + RING * TM * TK);
-    int *eb_s = ea_s + TM;                         // exponents / bias of this tile's BN stacked columns: fetched at the start,
-    float *bias_s = reinterpret_cast<float *>(eb_s + BN);   //   read in the epilogue without a global round trip
+    int *eb_s = ea_s + TM;
+    float *bias_s = reinterpret_cast<float *>(eb_s + BN);
+    // ... and the landing area of the NEXT tile's scalars: requested by LDS-DMA before the current tile's epilogue (no register
+    // lives across it for them), turned into the arrays above by tile_open() once that epilogue is through
+    float *pre_rm_s = bias_s + BN;                 // [NT] row maximum of every thread's A row
+    float *pre_ear_s = pre_rm_s + NT;              // [TM] row maxima of the tile's rows
+    int *pre_eb_s = reinterpret_cast<int *>(pre_ear_s + TM);      // [BN]
+    float *pre_bias_s = reinterpret_cast<float *>(pre_eb_s + BN); // [BN]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / (BN / 64), wn = wave % (BN / 64);
-    // XCD-aware order: every XCD walks a contiguous range of row tiles (n fastest)
+    // Thread coordinates.  Re-derived at the top of every tile from an OPAQUE copy of threadIdx.x (rethread()): everything
+    // computed from them -- LDS addresses, window offsets, the epilogue's address arithmetic -- is then per-tile work the
+    // compiler cannot hoist out of the persistent loop, where it would occupy registers across a k loop that has none to
+    // spare (hoisted, 25-58 VGPRs spilled around it; re-derived, a few dozen integer instructions per 60 k-cycle tile).
+    int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int wm = wave / (BN / 64), wn = wave % (BN / 64);
+    // PERSISTENT workgroups, XCD-aware: workgroup b lives on XCD b & 7 and walks every (gridDim.x / 8)-th tile of that XCD's
+    // contiguous range of row tiles (n fastest).  Before a tile's epilogue the workgroup requests the NEXT tile's first B
+    // planes and A windows: the HBM round trip that used to open every tile (7-8 k cycles of 60 k) runs under the epilogue.
     const int tiles = g.tiles_m * g.tiles_n;
-    int tile = blockIdx.x;
-    {
-        const int cpx = tiles >> 3, rem = tiles & 7;
-        const int xcd = tile & 7, slot = tile >> 3;
-        tile = xcd * cpx + min(xcd, rem) + slot;
-    }
-    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
-    const long m0 = (long)tm * TM;
-    const int n0 = tn * BN;
+    const int cpx = tiles >> 3, rem = tiles & 7, xcd = blockIdx.x & 7;
+    const int xcd_first = xcd * cpx + min(xcd, rem), xcd_count = cpx + (xcd < rem ? 1 : 0);
+    const int slot_stride = max(1, (int)gridDim.x >> 3);
+    int slot = blockIdx.x >> 3;
+    if (slot >= xcd_count) return;                           // (workgroup-uniform)
 
-    if (t < TM) ea_s[t] = scale_exponent(g.a_rowmax[min(m0 + t, g.m - 1)]);
-    if (t < BN) {
-        eb_s[t] = g.eb[n0 + t];
-        float bv = 0.f;
-        if (g.bias) {
-            if constexpr (EPI == EPI_GATE) {       // stacked column s of the tile: group (s / 32) & 1, output column (s / 64) * 32 + s % 32
-                const int d = g.n / 2, oc = min((n0 >> 1) + (t >> 6) * 32 + (t & 31), d - 1);
-                bv = g.bias[((t >> 5) & 1) * d + oc];
-            } else {
-                bv = g.bias[min(n0 + t, g.n - 1)];
-            }
-        }
-        bias_s[t] = bv;
-    }
-    const int arow = t / TPR, akc = t % TPR;                 // this thread's row / k chunk of the A tile
-    const long grow = min(m0 + arow, g.m - 1);               // clamped: rows past m are computed and never stored
-    const int ea = scale_exponent(g.a_rowmax[grow]);
+    int arow = t / TPR, akc = t % TPR;                       // this thread's row / k chunk of the A tile
+    auto rethread = [&]() {
+        int t_o = threadIdx.x;
+        asm volatile("" : "+v"(t_o));
+        t = t_o; lane = t & 63; wave = t >> 6;
+        wm = wave / (BN / 64); wn = wave % (BN / 64);
+        arow = t / TPR; akc = t % TPR;
+    };
+    // ---- per-tile state (set by setup(): the tile being computed, or -- from just before its epilogue on -- the next one)
+    long m0 = 0, grow = 0;
+    int n0 = 0, ea = 0;
 
     f32x16 acc[2][2], cor[ONE ? 1 : 2][ONE ? 1 : 2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.f;
-                if constexpr (!ONE) cor[i][j][r] = 0.f;
-            }
 
     // ONE branch-free load path for every tile of every panel (aligned or not, full or partial): a 16-byte window per
     // thread, its address clamped to the panel's last valid window (rows past m reuse row m-1, never stored; a window
@@ -240,7 +234,7 @@ void gemm_tall_kernel(TallArgs g) {
     const unsigned long pa##P = reinterpret_cast<unsigned long>((P < g.n_panels) ? g.a[P] : g.a[0]);              \
     const long ld##P = (P < g.n_panels) ? g.lda[P] : g.lda[0];                                                     \
     const int kw##P = (P < g.n_panels) ? g.ka[P] : g.ka[0];                                                        \
-    const unsigned long rowp##P = pa##P + 4ul * (unsigned long)(grow * ld##P + akc * EPT);                          \
+    unsigned long rowp##P = 0;                                                                                      \
     const unsigned long lastw##P = pa##P + 4ul * (unsigned long)((g.m - 1) * ld##P + kw##P - 4);
     LKG_PANEL(0)
     LKG_PANEL(1)
@@ -249,7 +243,50 @@ void gemm_tall_kernel(TallArgs g) {
     const int n_tiles = g.ktiles_total;
 
     typedef __attribute__((address_space(3))) void lds_void;
-    const uint4 *bsrc = reinterpret_cast<const uint4 *>(g.bp) + (long)tn * g.ktiles_total * (2 * BPL / 8) + t;
+    const uint4 *bsrc = nullptr;
+    // the registers that depend on the tile (pure integer arithmetic: re-derived rather than kept across an epilogue)
+    auto tile_regs = [&](int slot_) {
+        const int tile = xcd_first + slot_;
+        const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+        m0 = (long)tm * TM;
+        n0 = tn * BN;
+        grow = min(m0 + arow, g.m - 1);                       // clamped: rows past m are computed and never stored
+        rowp0 = pa0 + 4ul * (unsigned long)(grow * ld0 + akc * EPT);
+        rowp1 = pa1 + 4ul * (unsigned long)(grow * ld1 + akc * EPT);
+        rowp2 = pa2 + 4ul * (unsigned long)(grow * ld2 + akc * EPT);
+        bsrc = reinterpret_cast<const uint4 *>(g.bp) + (long)tn * g.ktiles_total * (2 * BPL / 8) + t;
+    };
+    // the tile's scalars from global memory: requested here (before the previous tile's epilogue) by LDS-DMA, one dword per
+    // lane into the landing area; every thread reads back what its own wave requested (tile_open)
+    auto tile_prefetch = [&]() {
+        typedef __attribute__((address_space(1))) const unsigned gu1;
+        auto dma4 = [&](const void *src, void *dst_wave) {
+            __builtin_amdgcn_global_load_lds((gu1 *)src, (lds_void *)dst_wave, 4, 0, 0);
+        };
+        dma4(g.a_rowmax + grow, pre_rm_s + wave * 64);
+        if (wave < TM / 64) dma4(g.a_rowmax + min(m0 + t, g.m - 1), pre_ear_s + wave * 64);       // (wave-uniform)
+        if (wave < BN / 64) {
+            dma4(g.eb + n0 + t, pre_eb_s + wave * 64);
+            if (g.bias) {
+                int idx;
+                if constexpr (EPI == EPI_GATE) {   // stacked column s of the tile: group (s / 32) & 1, output column (s / 64) * 32 + s % 32
+                    const int d = g.n / 2, oc = min((n0 >> 1) + (t >> 6) * 32 + (t & 31), d - 1);
+                    idx = ((t >> 5) & 1) * d + oc;
+                } else {
+                    idx = min(n0 + t, g.n - 1);
+                }
+                dma4(g.bias + idx, pre_bias_s + wave * 64);
+            }
+        }
+    };
+    auto tile_open = [&]() {                       // (after the previous epilogue: its LDS scalars may be overwritten now)
+        ea = scale_exponent(pre_rm_s[t]);
+        if (t < TM) ea_s[t] = scale_exponent(pre_ear_s[t]);
+        if (t < BN) {
+            eb_s[t] = pre_eb_s[t];
+            bias_s[t] = g.bias ? pre_bias_s[t] : 0.f;
+        }
+    };
 
     // ---- loads: LDS-DMA only (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR destination).  B's planes are
     // ready-made LDS images, so a tile is a straight copy into the other buffer; A's raw f32 windows go into a RING-deep
@@ -261,9 +298,14 @@ void gemm_tall_kernel(TallArgs g) {
     // (gt >= kt1 ? ... : ...) became a lookup table in private memory.  The staging side walks the same sequence
     // RING - 1 tiles behind (wave-uniform scalars), the per-thread window shifts travel in a small bit FIFO.
     int f_gt = 0, f_tk = 0, f_panel = 0, f_nt = g.ktiles[0];
-    unsigned long f_rowp = rowp0, f_lastw = lastw0;
+    unsigned long f_rowp = 0, f_lastw = lastw0;
     int s_gt = 0, s_tk = 0, s_panel = 0, s_nt = g.ktiles[0], s_kp = kw0;
     unsigned sh_fifo = 0;                          // 4 bits per tile in flight: 2 per window
+    auto reset_walks = [&]() {                     // (a new tile: both walks start over at its first k tile)
+        f_gt = f_tk = f_panel = 0; f_nt = g.ktiles[0]; f_rowp = rowp0; f_lastw = lastw0;
+        s_gt = s_tk = s_panel = 0; s_nt = g.ktiles[0]; s_kp = kw0;
+        sh_fifo = 0;
+    };
     unsigned long a_ptr[NA];                       // the windows of the tile the next issue_a requests
     // (all scalar bookkeeping -- the two walks -- happens in plan_a / plan_stage, ahead of the step's one basic block of
     // barrier, DMA issue, MFMAs and split: a branch inside would keep the scheduler from mixing the split into the MFMAs)
@@ -468,150 +510,236 @@ void gemm_tall_kernel(TallArgs g) {
         }
     };
 
+    auto epilogue = [&](const long m0, const int n0) {
+    // ---- epilogue (of the tile whose numbers are handed in: by then setup() may describe the next one).  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
+        // holds ONE column of 16 rows.  Written as it stands that is 16 dword stores per tile (two 128-byte runs per
+        // instruction); instead every wave turns its tile through a private 4 KB of the (now free) staging LDS and stores
+        // 16 bytes per lane, 8 rows x 128 B per instruction -- 4 stores per tile.
+        float *ts = reinterpret_cast<float *>(smem) + wave * 1024;
+        auto put = [&](const float(&v)[16]) {
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) ts[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[r];
+        };
+        // rows row0 .. row0 + 31 (global), columns col0 .. col0 + 31 of `base` (n_cols wide): out = ts (+ beta * old)
+        auto flush = [&](float *base, long ld, long row0, int col0, int n_cols, float beta) {
+            const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+            const int col = col0 + 4 * (lane & 7);
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long row = row0 + 8 * q + (lane >> 3);
+                float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+                if (row >= g.m) continue;
+                float *dst = base + row * ld + col;
+                if (vec && col + 3 < n_cols) {
+                    if (beta != 0.f) {
+                        const float4 o = *reinterpret_cast<const float4 *>(dst);
+                        v.x = fmaf(beta, o.x, v.x); v.y = fmaf(beta, o.y, v.y); v.z = fmaf(beta, o.z, v.z); v.w = fmaf(beta, o.w, v.w);
+                    }
+                    *reinterpret_cast<float4 *>(dst) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col + k < n_cols) dst[k] = beta != 0.f ? fmaf(beta, dst[k], e[k]) : e[k];
+                }
+            }
+        };
+        // the same for rows 16 h .. 16 h + 15 of the block (8 values per lane)
+        auto put_half = [&](const float(&v)[8], int h) {
+    #pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * h + q;
+                ts[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[q];
+            }
+        };
+        auto flush_half = [&](float *base, long ld, long row0, int col0, int n_cols, int h) {
+            const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+            const int col = col0 + 4 * (lane & 7);
+    #pragma unroll
+            for (int q = 2 * h; q < 2 * h + 2; ++q) {
+                const long row = row0 + 8 * q + (lane >> 3);
+                const float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+                if (row >= g.m) continue;
+                float *dst = base + row * ld + col;
+                if (vec && col + 3 < n_cols) {
+                    *reinterpret_cast<float4 *>(dst) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col + k < n_cols) dst[k] = e[k];
+                }
+            }
+        };
+        if constexpr (EPI == EPI_PLAIN) {
+            float bias_v[2];
+            int eb_v[2];
+    #pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                eb_v[j] = eb_s[wn * 64 + j * 32 + (lane & 31)];
+                bias_v[j] = bias_s[wn * 64 + j * 32 + (lane & 31)];
+            }
+    #pragma unroll
+            for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col0 = n0 + wn * 64 + j * 32;
+                    if (col0 >= g.n) continue;                                // wave-uniform
+                    const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
+                    float out[16];
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r];
+                        if constexpr (!ONE) v = fmaf(cor[i][j][r], 1.f / 2048.f, v);
+                        out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
+                    }
+                    put(out);
+                    flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
+                    __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
+                }
+        } else {
+            // gate: tile column block j = 0 holds g, j = 1 holds z of the SAME output column
+            const int d = g.n / 2;
+            const int col0 = (n0 >> 1) + wn * 32;
+            const int col = col0 + (lane & 31);
+            if (col0 < d) {                                                   // wave-uniform
+                const int cc = min(col, d - 1);                               // lanes past d compute on a clamped column, never stored
+                const int ebg = eb_s[wn * 64 + (lane & 31)], ebz = eb_s[wn * 64 + 32 + (lane & 31)];
+                const float bg = bias_s[wn * 64 + (lane & 31)], bz = bias_s[wn * 64 + 32 + (lane & 31)];
+    #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
+                    const long row0 = m0 + wm * 64 + i * 32;
+                    // 16 rows at a time (registers r = 8 h .. 8 h + 7 are rows 16 h .. 16 h + 15 of the 32 x 32 block): half the
+                    // temporaries of a whole block at once, next to 64 accumulators
+    #pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float xv[8];
+    #pragma unroll
+                        // x[rows of the tile, this lane's output column]: re-read (two 128-byte runs per instruction; +n d 4 bytes of
+                        // traffic).  Round 2 kept these values in a 66 KB LDS stash filled while the x panel was staged: one workgroup
+                        // per CU then, and the k loop of a lone workgroup leaves the matrix pipe 38 % busy -- two per CU: GateMul
+                        // forward 1 M x (256+2+300) 2.73 -> 2.46 ms, forward + backward 8.5 -> 7.9 ms.
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = 8 * h + q;
+                            xv[q] = g.x[min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1) * g.ldx + cc];
+                        }
+                        float ov[8], gv[8], zv[8];
+    #pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int r = 8 * h + q;
+                            const int dr = (r & 3) + 8 * (r >> 2);
+                            const int e = ea_s[lr0 + dr];
+                            float gs = acc[i][0][r], zs = acc[i][1][r];
+                            if constexpr (!ONE) {
+                                gs = fmaf(cor[i][0][r], 1.f / 2048.f, gs);
+                                zs = fmaf(cor[i][1][r], 1.f / 2048.f, zs);
+                            }
+                            const float gp = ldexpf(gs, -(e + ebg)) + bg;
+                            const float zp = ldexpf(zs, -(e + ebz)) + bz;
+                            gv[q] = tanh_fast(gp);
+                            zv[q] = sigmoid_fast(zp);
+                            ov[q] = fmaf(zv[q], gv[q] - xv[q], xv[q]);        // (1 - z) x + z g
+                        }
+                        put_half(ov, h);
+                        flush_half(g.c, g.ldc, row0, col0, d, h);
+                        if (g.g_out) {
+                            put_half(gv, h);
+                            flush_half(g.g_out, g.ldg, row0, col0, d, h);
+                        }
+                        if (g.z_out) {
+                            put_half(zv, h);
+                            flush_half(g.z_out, g.ldz, row0, col0, d, h);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+    };
+
     // One barrier per step, no branch in the loop (the accumulators never meet a control-flow join).  Step t: wait for
     // this wave's B(t) and A(t+1) pieces + its plane writes, barrier (tile t complete in buffer t & 1, nobody still reads
     // the other one) -> LDS-DMA of B(t+1) into the other buffer and of A(t+3) into the ring slot tile t just left ->
     // fragment reads + 12 MFMAs of tile t, with the split of tile t+1 (ring -> planes of the other buffer) in their
     // shadow.  Past the last tile the staged / fetched tiles are duplicates of the last one (in bounds, never read).
 #define LKG_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    issue_b(0, smem);
-    plan_a(0); issue_a(0);
-    plan_a(1); issue_a(1);
-    plan_a(2); issue_a(2);
-    if constexpr (NA == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    plan_stage();
-    ring_read(0);                                  // (its own pieces: no barrier between the DMA and the read-back)
-    ring_wait();
-    stage_only(smem);
-    int slot_f = 0, slot_s = 1;                    // ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged
-    for (int gt = 0; gt < n_tiles; ++gt) {
-        plan_a(2);
-        plan_stage();
-        _Float16 *cur = smem + (gt & 1) * BUF, *nxt = smem + ((gt + 1) & 1) * BUF;
-        if constexpr (NA == 1) LKG_WAIT_BARRIER(1); else LKG_WAIT_BARRIER(2);
-        ring_read(slot_s);
-        issue_b(gt + 1, nxt);
-        issue_a(slot_f);
-        ring_wait();
-        step(cur, nxt, true);
-        slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
-        slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
-    }
-#undef LKG_WAIT_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the duplicate tiles still in flight target the ring
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
-    // holds ONE column of 16 rows.  Written as it stands that is 16 dword stores per tile (two 128-byte runs per
-    // instruction); instead every wave turns its tile through a private 4 KB of the (now free) staging LDS and stores
-    // 16 bytes per lane, 8 rows x 128 B per instruction -- 4 stores per tile.
-    __syncthreads();                                           // every wave is done reading the staging buffers
-    float *ts = reinterpret_cast<float *>(smem) + wave * 1024;
-    auto put = [&](const float(&v)[16]) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ts[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[r];
+    // A tile's FIRST k step reads buffer 1: the epilogue's transposes use the first 32 KB of the staging LDS (buffer 0 and the A
+    // planes of buffer 1), so the next tile's first B planes -- requested before that epilogue -- land beyond them.
+    auto request_first = [&](bool issue) {         // the loads that open a tile: B(0) -> buffer 1, A(0..2) -> the ring
+        reset_walks();                             // (issue = false: the same walk, nothing requested -- re-derives the state)
+        if (issue) issue_b(0, smem + BUF);
+        plan_a(0); if (issue) issue_a(0);
+        plan_a(1); if (issue) issue_a(1);
+        plan_a(2); if (issue) issue_a(2);
     };
-    // rows row0 .. row0 + 31 (global), columns col0 .. col0 + 31 of `base` (n_cols wide): out = ts (+ beta * old)
-    auto flush = [&](float *base, long ld, long row0, int col0, int n_cols, float beta) {
-        const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-        const int col = col0 + 4 * (lane & 7);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long row = row0 + 8 * q + (lane >> 3);
-            float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
-            if (row >= g.m) continue;
-            float *dst = base + row * ld + col;
-            if (vec && col + 3 < n_cols) {
-                if (beta != 0.f) {
-                    const float4 o = *reinterpret_cast<const float4 *>(dst);
-                    v.x = fmaf(beta, o.x, v.x); v.y = fmaf(beta, o.y, v.y); v.z = fmaf(beta, o.z, v.z); v.w = fmaf(beta, o.w, v.w);
-                }
-                *reinterpret_cast<float4 *>(dst) = v;
-            } else {
-                const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (col + k < n_cols) dst[k] = beta != 0.f ? fmaf(beta, dst[k], e[k]) : e[k];
-            }
-        }
-    };
-    if constexpr (EPI == EPI_PLAIN) {
-        float bias_v[2];
-        int eb_v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            eb_v[j] = eb_s[wn * 64 + j * 32 + (lane & 31)];
-            bias_v[j] = bias_s[wn * 64 + j * 32 + (lane & 31)];
+    tile_regs(slot);
+    tile_prefetch();
+    request_first(true);
+    bool first_tile = true;
+    while (true) {
+        if (!first_tile) {                         // (workgroup-uniform) re-derive what the epilogue was not asked to carry
+            rethread();
+            tile_regs(slot);
+            request_first(false);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col0 = n0 + wn * 64 + j * 32;
-                if (col0 >= g.n) continue;                                // wave-uniform
-                const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
-                float out[16];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r];
-                    if constexpr (!ONE) v = fmaf(cor[i][j][r], 1.f / 2048.f, v);
-                    out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
+                    acc[i][j][r] = 0.f;
+                    if constexpr (!ONE) cor[i][j][r] = 0.f;
                 }
-                put(out);
-                flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
-                __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
-            }
-    } else {
-        // gate: tile column block j = 0 holds g, j = 1 holds z of the SAME output column
-        const int d = g.n / 2;
-        const int col0 = (n0 >> 1) + wn * 32;
-        const int col = col0 + (lane & 31);
-        if (col0 < d) {                                                   // wave-uniform
-            const int cc = min(col, d - 1);                               // lanes past d compute on a clamped column, never stored
-            const int ebg = eb_s[wn * 64 + (lane & 31)], ebz = eb_s[wn * 64 + 32 + (lane & 31)];
-            const float bg = bias_s[wn * 64 + (lane & 31)], bz = bias_s[wn * 64 + 32 + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
-                float xv[16];
-#pragma unroll
-                // x[rows of the tile, this lane's output column]: re-read (two 128-byte runs per instruction; +n d 4 bytes of traffic).
-                // Round 2 kept these values in a 66 KB LDS stash filled while the x panel was staged: one workgroup per CU
-                // then, and the k loop of a lone workgroup leaves the matrix pipe 38 % busy -- two per CU: GateMul forward
-                // 1 M x (256+2+300) 2.73 -> 2.46 ms, forward + backward 8.5 -> 7.9 ms.
-                for (int r = 0; r < 16; ++r)
-                    xv[r] = g.x[min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1) * g.ldx + cc];
-                float ov[16], gv[16], zv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    const int e = ea_s[lr0 + dr];
-                    float gs = acc[i][0][r], zs = acc[i][1][r];
-                    if constexpr (!ONE) {
-                        gs = fmaf(cor[i][0][r], 1.f / 2048.f, gs);
-                        zs = fmaf(cor[i][1][r], 1.f / 2048.f, zs);
-                    }
-                    const float gp = ldexpf(gs, -(e + ebg)) + bg;
-                    const float zp = ldexpf(zs, -(e + ebz)) + bz;
-                    gv[r] = tanh_fast(gp);
-                    zv[r] = sigmoid_fast(zp);
-                    ov[r] = fmaf(zv[r], gv[r] - xv[r], xv[r]);        // (1 - z) x + z g
-                }
-                const long row0 = m0 + wm * 64 + i * 32;
-                put(ov);
-                flush(g.c, g.ldc, row0, col0, d, 0.f);
-                if (g.g_out) {
-                    put(gv);
-                    flush(g.g_out, g.ldg, row0, col0, d, 0.f);
-                }
-                if (g.z_out) {
-                    put(zv);
-                    flush(g.z_out, g.ldz, row0, col0, d, 0.f);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        if (first_tile) {                          // the oldest loads only: A(1), A(2) stay in flight
+            if constexpr (NA == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            // requested before the previous epilogue, whose stores are younger: vmcnt counts loads and stores in one counter
+            // and they retire out of order with each other, so only vmcnt(0) says that the loads are in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        first_tile = false;
+        tile_open();                               // (the scalars' DMAs are the oldest requests: in by now)
+        plan_stage();
+        ring_read(0);                              // (its own pieces: no barrier between the DMA and the read-back)
+        ring_wait();
+        stage_only(smem + BUF);
+        int slot_f = 0, slot_s = 1;                // ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged
+        for (int gt = 0; gt < n_tiles; ++gt) {
+            plan_a(2);
+            plan_stage();
+            _Float16 *cur = smem + ((gt + 1) & 1) * BUF, *nxt = smem + (gt & 1) * BUF;
+            if constexpr (NA == 1) LKG_WAIT_BARRIER(1); else LKG_WAIT_BARRIER(2);
+            ring_read(slot_s);
+            issue_b(gt + 1, nxt);
+            issue_a(slot_f);
+            ring_wait();
+            step(cur, nxt, true);
+            slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
+            slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the duplicate tiles still in flight target the ring / buffers
+
+        const long e_m0 = m0;                                  // (the epilogue's tile; tile_regs() moves on to the next one)
+        const int e_n0 = n0;
+        __syncthreads();                                       // every wave is done reading the staging buffers and the ring
+        rethread();                                            // (what follows re-derives its coordinates: none live across the k loop)
+        slot += slot_stride;
+        const bool more = slot < xcd_count;                    // (workgroup-uniform)
+        if (more) {
+            tile_regs(slot);
+            tile_prefetch();
+            request_first(true);
+        }
+        epilogue(e_m0, e_n0);
+        if (!more) break;
+        __syncthreads();     // the transposes are done with buffer 1's A planes and the tile's LDS scalars: the next tile moves in
     }
+#undef LKG_WAIT_BARRIER
 }
 
 // out[i] = max_j |x[i, j]|   (accumulate: max with the value already there).  One wave per row.
@@ -739,15 +867,17 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
         hipLaunchKernelGGL((b_planes_kernel<128>), dim3(g.tiles_n * g.ktiles_total), dim3(128), 0, s, bd, g.ktiles_total, eb, planes);
     g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    const long n_tiles_mn = (long)g.tiles_m * g.tiles_n;
     auto lds_bytes = [](int bn_) {
-        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4;
+        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4 +
+               (2 * bn_ + TM + 2 * bn_) * 4;       // + the landing area of the next tile's scalars
     };
     const int lds = lds_bytes(bn);
     const bool one = tall_variant() != 0;
 #define LKG_TALL_GO(BN_, EPI_, ONE_)                                                                                   \
     do {                                                                                                               \
         static bool raised = false;                                                                                    \
+        static int resident = 0;      /* workgroups of this kernel the device holds at once (occupancy x CUs) */       \
         if (!raised && lds > 48 * 1024) {                                                                              \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {                  \
@@ -756,6 +886,19 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
             }                                                                                                          \
             raised = true;                                                                                             \
         }                                                                                                              \
+        if (!resident) {                                                                                               \
+            int dev_ = 0, per_cu_ = 0, cus_ = 0;                                                                       \
+            if (hipGetDevice(&dev_) != hipSuccess ||                                                                   \
+                hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess ||             \
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_kernel<BN_, EPI_, ONE_>, 2 * BN_,     \
+                                                             lds) != hipSuccess || per_cu_ < 1 || cus_ < 1) {          \
+                lkg_set_error("lkg_gemm_tall_f32: cannot size the persistent grid");                                   \
+                return LKG_ERR_HIP;                                                                                    \
+            }                                                                                                          \
+            resident = std::max(8, per_cu_ * cus_ / 8 * 8);                                                            \
+        }                                                                                                              \
+        /* persistent workgroups: one stripe of tiles per resident workgroup, a multiple of 8 (one per XCD) */        \
+        const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, resident));                                 \
         hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_>), grid, dim3(2 * BN_), lds, s, g);                       \
     } while (0)
     if (epilogue == EPI_GATE) {
