@@ -191,6 +191,8 @@ struct SpmmExtra {
     const unsigned char *self_rows;   // nullable: the same promise for `self`
     unsigned char *out_rows;          // nullable (with x_rows): out_rows[i] = 1 where row i received a contribution; the other
                                       //   rows are NOT written (out is a table the caller keeps all-zero there)
+    const int *row_list;              // nullable: the ordinary waves take THESE rows (the rows that hold entries); the others are
+    int n_list;                       //   spmm_listless_rows_kernel's
     __device__ __forceinline__ const float *add2_row(long row) const {
         return add2 && (!add2_rows || add2_rows[row]) ? add2 + row * ld_add2 : nullptr;
     }
@@ -240,7 +242,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
         row = long_rows[bid];
     } else {
         row = (bid - n_long) * 4 + w;
-        if (row >= n_rows) return;
+        if (ex.row_list) {               // a structure of mostly EMPTY rows: one wave per row that holds entries
+            if (row >= ex.n_list) return;
+            row = ex.row_list[row];
+        } else if (row >= n_rows) {
+            return;
+        }
     }
     const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
     const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
@@ -498,6 +505,29 @@ __global__ __launch_bounds__(256) void spmm_flagged4_kernel(int n_rows, int nchu
     }
 }
 
+// The rows WITHOUT entries of a structure that is mostly such rows (BASELINE config[0]'s shape: 766 k entity rows, 84 % of them
+// never a head): out = (self +) (add2 +) 0, the row copy and the row maximum -- a streaming pass, one 16-byte (or 4-byte)
+// chunk per thread, instead of one wave (a workgroup slot, a rowptr round trip) per empty row: with one wave per row the
+// launch was bound by the rate at which workgroups start, not by HBM (0.28 ms for 0.46 GB).
+template <typename V>
+__global__ __launch_bounds__(256) void spmm_listless_rows_kernel(long n_list, const int *__restrict__ rows, int nchunk,
+                                                                  float *__restrict__ out, long ldo,
+                                                                  const float *__restrict__ self, long ld_self, SpmmExtra ex) {
+    using ops = vec_ops<V>;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_list * nchunk) return;
+    const long row = rows[idx / nchunk];
+    const int chunk = (int)(idx % nchunk);
+    V acc = ops::zero();
+    if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + row * ld_self)[chunk]);
+    if (const float *a2 = ex.add2_row(row)) ops::fma(acc, 1.f, reinterpret_cast<const V *>(a2)[chunk]);
+    reinterpret_cast<V *>(out + row * ldo)[chunk] = acc;
+    if (ex.copy_dst)
+        reinterpret_cast<V *>(ex.copy_dst + row * ex.ld_copy_dst)[chunk] =
+            reinterpret_cast<const V *>(ex.copy_src + row * ex.ld_copy_src)[chunk];
+    if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(acc)));
+}
+
 template <typename V, int LPE, int U, bool FULL>
 int launch_grouped(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
                    int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows,
@@ -516,7 +546,7 @@ template <typename V, int LPE, int CPL, int U, bool FULL>
 int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
            int64_t ldx, float *out, int64_t ldo, const float *self, int64_t ld_self, const int *long_rows, int n_long,
            int long_thresh, int n_slabs, int slab_cols, const SpmmExtra &ex, hipStream_t s) {
-    const int64_t blocks = (n_rows + 3) / 4 + n_long;
+    const int64_t blocks = ((ex.row_list ? (int64_t)ex.n_list : n_rows) + 3) / 4 + n_long;
     LKG_REQUIRE(blocks * n_slabs * 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large (%lld workgroups)",
                 (long long)(blocks * n_slabs));
     if constexpr (std::is_same<V, float4>::value) {
@@ -557,17 +587,17 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
                                                long_rows, n_long, long_thresh, n_slabs, slab_cols, ex, s)
     // rows of <= 32 floats: 8 rows per wave (see spmm_csr_grouped_kernel); a row-sparse x -- the long rows behind
     // spmm_flagged4_kernel -- stays on the wave-per-row kernel's flagged form
-    if (nchunk <= 8 && !ex.x_rows)
+    if (nchunk <= 8 && !ex.x_rows && !ex.row_list)
         return (nchunk == 8) ? launch_grouped<V, 8, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                             ld_self, long_rows, n_long, long_thresh, ex, s)
                              : launch_grouped<V, 8, 8, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                              ld_self, long_rows, n_long, long_thresh, ex, s);
     if constexpr (std::is_same<V, float4>::value) {
         // experiment (LKG_SPMM_GROUPED_CHUNKS=16|32): several rows per wave for 64- / 128-column rows too
-        if (!ex.x_rows && n_slabs == 1 && nchunk == 16 && grouped_max_chunks() >= 16)
+        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 16 && grouped_max_chunks() >= 16)
             return launch_grouped<V, 16, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
                                                   n_long, long_thresh, ex, s);
-        if (!ex.x_rows && n_slabs == 1 && nchunk == 32 && grouped_max_chunks() >= 32)
+        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 32 && grouped_max_chunks() >= 32)
             return launch_grouped<V, 32, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
                                                   n_long, long_thresh, ex, s);
     }
@@ -592,7 +622,9 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                                       const uint8_t *add2_rows, const float *copy_src, int64_t ld_copy_src,
                                       float *copy_dst, int64_t ld_copy_dst, float *rowmax_out, const uint8_t *x_rows,
                                       const uint8_t *self_rows, uint8_t *out_rows, const int32_t *long_rows,
-                                      int32_t n_long, int32_t long_thresh, void *stream) {
+                                      int32_t n_long, int32_t long_thresh, const int32_t *rows_with_entries,
+                                      int64_t n_rows_with_entries, const int32_t *rows_without_entries,
+                                      int64_t n_rows_without_entries, void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "lkg_spmm_csr_f32: n_rows %lld out of range", (long long)n_rows);
     LKG_REQUIRE(d > 0, "lkg_spmm_csr_f32: d must be positive (got %d)", d);
     LKG_REQUIRE(ldx >= d && ldo >= d, "lkg_spmm_csr_f32: row strides (%lld, %lld) smaller than d=%d", (long long)ldx,
@@ -623,8 +655,29 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         lkg_set_error("lkg_spmm_csr_fused_f32: hipMemsetAsync failed");
         return LKG_ERR_HIP;
     }
+    const bool listed = rows_with_entries != nullptr;
+    LKG_REQUIRE(!listed || (rows_without_entries && !x_rows && !out_rows && n_rows_with_entries >= 0 &&
+                            n_rows_without_entries >= 0 && n_rows_with_entries + n_rows_without_entries == n_rows),
+                "lkg_spmm_csr_fused_f32: the row lists must partition the %lld rows (and exclude x_rows / out_rows)",
+                (long long)n_rows);
     const SpmmExtra ex{add2, (long)ld_add2, add2 ? add2_rows : nullptr, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,
-                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows};
+                       (long)ld_copy_dst, reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows,
+                       listed ? rows_with_entries : nullptr, listed ? (int)n_rows_with_entries : 0};
+    if (listed && n_rows_without_entries > 0) {      // the rows without entries: one streaming pass (all column slabs at once)
+        const int nchunk_all = vec ? d / 4 : d;
+        const int64_t threads = n_rows_without_entries * nchunk_all;
+        LKG_REQUIRE((threads + 255) / 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large");
+        if (vec)
+            hipLaunchKernelGGL((spmm_listless_rows_kernel<float4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                               (long)n_rows_without_entries, rows_without_entries, nchunk_all, out, (long)ldo, self,
+                               (long)ld_self, ex);
+        else
+            hipLaunchKernelGGL((spmm_listless_rows_kernel<float>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                               (long)n_rows_without_entries, rows_without_entries, nchunk_all, out, (long)ldo, self,
+                               (long)ld_self, ex);
+        LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
+        if (n_rows_with_entries == 0 && n_long == 0) return LKG_OK;
+    }
     // Column slabs.  Rows wider than 128 floats are aggregated 128 columns (512 B per gathered row) at a time:
     // measured on MI355X the slab form is 10-30 % faster than one full-width pass (1 M x 256: 1.83 -> 1.56 ms,
     // 1 M x 512: 4.13 -> 3.10 ms, 2 M x 256: 4.09 -> 3.70 ms) -- a half-wave per row keeps two rows per wave in
@@ -656,7 +709,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         for (int c0 = 0; c0 < d; c0 += 256) {
             const int dc = min(256, d - c0);
             const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr, nullptr, 0, nullptr, 0, nullptr,
-                                x_rows, self ? self_rows : nullptr, out_rows};
+                                x_rows, self ? self_rows : nullptr, out_rows, nullptr, 0};
             const int rc = dispatch<float4>(0, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo, self ? self + c0 : nullptr,
                                             ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s);
             if (rc != LKG_OK) return rc;
@@ -676,7 +729,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         const SpmmExtra exc{add2 ? add2 + c0 : nullptr, (long)ld_add2, add2 ? add2_rows : nullptr,
                             copy_dst ? copy_src + c0 : nullptr,
                             (long)ld_copy_src, copy_dst ? copy_dst + c0 : nullptr, (long)ld_copy_dst,
-                            reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows};
+                            reinterpret_cast<int *>(rowmax_out), x_rows, self ? self_rows : nullptr, out_rows, ex.row_list, ex.n_list};
         int rc = vec ? dispatch<float4>(n_rows, dc / 4, rowptr, col, val, x + c0, ldx, out + c0, ldo,
                                         self ? self + c0 : nullptr, ld_self, long_rows, n_long, long_thresh, 1, 0, exc, s)
                      : dispatch<float>(n_rows, dc, rowptr, col, val, x + c0, ldx, out + c0, ldo,
@@ -691,7 +744,8 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                 const float *self, int64_t ld_self, const int32_t *long_rows, int32_t n_long,
                                 int32_t long_thresh, void *stream) {
     return lkg_spmm_csr_fused_f32(n_rows, d, rowptr, col, val, x, ldx, out, ldo, self, ld_self, nullptr, 0, nullptr,
-                                  nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, long_rows, n_long, long_thresh, stream);
+                                  nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, long_rows, n_long, long_thresh,
+                                  nullptr, 0, nullptr, 0, stream);
 }
 
 // dst[i] = src[perm[i]]

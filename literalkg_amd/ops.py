@@ -135,7 +135,8 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
              copy: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              rowmax: Optional[torch.Tensor] = None, add2_rows: Optional[torch.Tensor] = None,
              x_rows: Optional[torch.Tensor] = None, self_rows: Optional[torch.Tensor] = None,
-             out_rows: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out_rows: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+             row_lists: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """out[i,:] = (add_self[i,:] +) (add2[i,:] +) sum_j val[j] * x[col[j] - x_row_offset, :] for the n_rows rows
     described by rowptr (a view into a longer rowptr is fine: its values index col/val directly).  x_row_offset lets
     a row-range shard hand over only ITS rows of x while col keeps global ids.  copy = (src, dst): the kernel's
@@ -143,7 +144,9 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
     x_rows / self_rows (uint8 per row of add2 / x / add_self): the operand is zero outside the flagged rows and is read
     there only (x_rows is indexed like x: by col - x_row_offset).  out_rows (uint8 per output row, with x_rows): receives
     1 where a row got a contribution; the other rows of ``out`` are NOT written (the caller keeps them zero).
-    bias (float32[d], instead of add2): the same row added to every output row."""
+    bias (float32[d], instead of add2): the same row added to every output row.  row_lists = (rows with entries, rows
+    without), int32, of a structure whose rows are mostly empty (KGStructure.row_lists): one wave per listed row, the empty
+    rows in one streaming pass; ignored with x_rows."""
     _need_gpu(x, val, rowptr, col)
     x = _f32_rows(x)
     d = x.shape[1]
@@ -172,7 +175,10 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
            _ld(add2) if add2 is not None else 0, N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
            N.ptr(rowmax), (x_rows.data_ptr() - x_row_offset) if x_rows is not None else None,
            N.ptr(self_rows if add_self is not None else None), N.ptr(out_rows), N.ptr(long_rows),
-           0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD, _stream())
+           0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
+           *((N.ptr(row_lists[0]), row_lists[0].numel(), N.ptr(row_lists[1]), row_lists[1].numel())
+             if (row_lists is not None and x_rows is None and row_lists[0].numel() + row_lists[1].numel() == n_rows)
+             else (None, 0, None, 0)), _stream())
     return out
 
 
@@ -672,7 +678,8 @@ class _Aggregate(Function):
         rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
         return tag_rowmax(spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
                                    add_self=ego if plus_self else None, rowmax=rm,
-                                   bias=bias.detach().contiguous() if bias is not None else None), rm)
+                                   bias=bias.detach().contiguous() if bias is not None else None,
+                                   row_lists=g.row_lists(False)), rm)
 
     @staticmethod
     def backward(ctx, grad):
@@ -709,7 +716,8 @@ class _Aggregate(Function):
             ent.unknown = False
             return tag_rows(out, RowSet(reached, [ids], unique=True)), None, None, None, None
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, grad, g.n, long_rows=g.long_rows(True),
-                        add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows), None, None, None, None
+                        add_self=grad if ctx.plus_self else None, x_rows=rows, self_rows=rows,
+                        row_lists=g.row_lists(True)), None, None, None, None
 
 
 def aggregate(ego: torch.Tensor, g: KGStructure, val: torch.Tensor, val_t: torch.Tensor,
@@ -737,7 +745,7 @@ class _AggregateKeep(Function):
             copy, kept = (ego, keep_dst), keep_dst
         rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
         side = spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
-                        add_self=ego if plus_self else None, copy=copy, rowmax=rm)
+                        add_self=ego if plus_self else None, copy=copy, rowmax=rm, row_lists=g.row_lists(False))
         return tag_rowmax(side, rm), kept          # kept may be the input itself: autograd aliases it as this node's output
 
     @staticmethod
@@ -771,7 +779,7 @@ class _AggregateKeep(Function):
             return tag_rows(out, RowSet(reached, [ids], unique=True)), None, None, None, None, None
         return spmm_raw(g.t_rowptr, g.t_col, ctx.val_t, g_side, g.n, long_rows=g.long_rows(True),
                         add_self=g_side if ctx.plus_self else None, add2=g_kept,
-                        add2_rows=_flags(rk), x_rows=rows, self_rows=rows), None, None, None, None, None
+                        add2_rows=_flags(rk), x_rows=rows, self_rows=rows, row_lists=g.row_lists(True)), None, None, None, None, None
 
 
 def aggregate_keep(ego, g: KGStructure, val, val_t, plus_self: bool = False, keep_dst: Optional[torch.Tensor] = None):
