@@ -1470,6 +1470,82 @@ def test_edge_cases_small_batches_dtypes_and_empty_graphs(L, ops, O, gpu_device)
                                                   device=gpu_device), 3)
 
 
+@pytest.mark.parametrize("d", [64, 256, 32, 30])
+def test_spmm_over_mostly_empty_rows_takes_the_row_lists(L, ops, gpu_device, d):
+    """A structure whose rows are mostly empty (the reference's sparse id spaces, dataloader.py:405-418) is aggregated row list
+    by row list: same bits as the one-wave-per-row launch, with every epilogue extra (self, second addend / bias row, row copy,
+    row maxima), on the 16-byte and the scalar path, forward and transpose."""
+    rng = np.random.default_rng(d)
+    n, e = 60_000, 40_000
+    used = rng.choice(n, 8_000, replace=False)
+    h, t, r = used[rng.integers(0, len(used), e)], rng.integers(0, n, e), rng.integers(0, 4, e)
+    h[:600] = used[0]                                           # one row beyond the long-row threshold
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    lists = g.row_lists(False)
+    assert lists is not None and lists[0].numel() + lists[1].numel() == n and lists[0].numel() <= 8_000
+    assert g.row_lists(True) is None or g.row_lists(True)[0].numel() + g.row_lists(True)[1].numel() == n
+    val = torch.rand(g.nnz, device=gpu_device)
+    val_t = ops.permute_values(val, g.t_perm)
+    x = torch.randn(n, d, device=gpu_device)
+    add2 = torch.randn(n, d, device=gpu_device)
+    bias = torch.randn(d, device=gpu_device)
+    for rowptr, col, v, transposed in ((g.rowptr, g.col, val, False), (g.t_rowptr, g.t_col, val_t, True)):
+        rl = g.row_lists(transposed)
+        if rl is None:
+            continue
+        long_rows = g.long_rows(transposed)
+        for kw in (dict(), dict(add_self=x), dict(add_self=x, add2=add2), dict(bias=bias), dict(add_self=x, want_copy=True),
+                   dict(add_self=x, want_rowmax=True)):
+            kw = dict(kw)
+            outs = []
+            for use in (None, rl):
+                k2 = {k_: v_ for k_, v_ in kw.items() if not k_.startswith("want_")}
+                cdst = torch.zeros(n, d, device=gpu_device) if kw.get("want_copy") else None
+                rm = torch.empty(n, device=gpu_device) if kw.get("want_rowmax") else None
+                out = torch.full((n, d), 7.0, device=gpu_device)
+                ops.spmm_raw(rowptr, col, v, x, n, out=out, long_rows=long_rows, row_lists=use,
+                             copy=(x, cdst) if cdst is not None else None, rowmax=rm, **k2)
+                outs.append((out, cdst, rm))
+            (o0, c0, m0), (o1, c1, m1) = outs
+            assert torch.equal(o0, o1), (d, transposed, sorted(kw))
+            assert c0 is None or (torch.equal(c0, c1) and torch.equal(c1, x))
+            assert m0 is None or torch.equal(m0, m1)
+
+
+def test_module_step_on_a_sparse_id_space_equals_the_unlisted_launches(L, O, gpu_device):
+    """BASELINE config[0]'s shape in small: most entity rows never occur as a head.  The module's step with the row lists
+    (default from 50 % empty rows on) equals the step with them switched off, bit for bit in the loss and to float-atomics
+    noise in the gradients."""
+    from literalkg_amd.synth import make_batch
+    from literalkg_amd import io
+    rng = np.random.default_rng(3)
+    n, e, dim = 50_000, 30_000, 64
+    used = rng.choice(n, 6_000, replace=False)
+    h, t, r = used[rng.integers(0, len(used), e)], used[rng.integers(0, len(used), e)], rng.integers(0, 16, e)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=1, aggregation_type="gcn",
+                        kg_l2loss_lambda=1e-4, device=gpu_device)
+    a_in = io.initial_a_in(n, h, t, r)
+    batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 100, 3, seed=2)]
+    res = []
+    saved = L.KGStructure.EMPTY_ROWS_LISTED_FROM
+    try:
+        for frac in (saved, 2.0):
+            L.KGStructure.EMPTY_ROWS_LISTED_FROM = frac
+            torch.manual_seed(1)
+            m = L.LiteralKG(cfg, n, 16, a_in).to(gpu_device).eval()
+            assert (m._attention().graph.row_lists(False) is not None) == (frac <= 1.0)
+            loss = m(*batch, device=gpu_device, mode="pre_training")
+            loss.backward()
+            res.append((float(loss.detach()), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}))
+    finally:
+        L.KGStructure.EMPTY_ROWS_LISTED_FROM = saved
+    (l1, g1), (l0, g0) = res
+    assert l1 == l0
+    for k in g0:
+        scale = float(g0[k].abs().max()) + 1e-30
+        assert float((g1[k] - g0[k]).abs().max()) <= 5e-5 * scale, k
+
+
 @pytest.mark.parametrize("kind", ["random-walk", "symmetric"])
 def test_device_laplacian_matches_the_reference_loader_and_the_host_form(L, gpu_device, kind):
     """io.initial_a_in on the device (radix-sort structure build + lkg_laplacian_device_f32) against the fixture the
