@@ -535,12 +535,14 @@ void gemm_tall_kernel(TallArgs g) {
                         const float4 o = *reinterpret_cast<const float4 *>(dst);
                         v.x = fmaf(beta, o.x, v.x); v.y = fmaf(beta, o.y, v.y); v.z = fmaf(beta, o.z, v.z); v.w = fmaf(beta, o.w, v.w);
                     }
-#ifdef LKG_TALL_NT_STORE          /* A/B switch (LKG_EXTRA_HIPCC_FLAGS=-DLKG_TALL_NT_STORE): streaming stores for C */
+                    // streaming (nontemporal) stores: C is far larger than the L2 and is not read again by this launch --
+                    // 1 M x 256: K = 64 0.376 -> 0.309 ms, K = 256 0.706 -> 0.694 ms (LKG_EXTRA_HIPCC_FLAGS=-DLKG_TALL_PLAIN_STORE: A/B)
+#ifdef LKG_TALL_PLAIN_STORE
+                    *reinterpret_cast<float4 *>(dst) = v;
+#else
                     typedef float nt4 __attribute__((ext_vector_type(4)));
                     const nt4 nv = {v.x, v.y, v.z, v.w};
                     __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(dst));
-#else
-                    *reinterpret_cast<float4 *>(dst) = v;
 #endif
                 } else {
                     const float e[4] = {v.x, v.y, v.z, v.w};
@@ -568,7 +570,13 @@ void gemm_tall_kernel(TallArgs g) {
                 if (row >= g.m) continue;
                 float *dst = base + row * ld + col;
                 if (vec && col + 3 < n_cols) {
+#ifdef LKG_TALL_PLAIN_STORE
                     *reinterpret_cast<float4 *>(dst) = v;
+#else
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 nv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(dst));
+#endif
                 } else {
                     const float e[4] = {v.x, v.y, v.z, v.w};
     #pragma unroll

@@ -509,23 +509,35 @@ __global__ __launch_bounds__(256) void spmm_flagged4_kernel(int n_rows, int nchu
 // never a head): out = (self +) (add2 +) 0, the row copy and the row maximum -- a streaming pass, one 16-byte (or 4-byte)
 // chunk per thread, instead of one wave (a workgroup slot, a rowptr round trip) per empty row: with one wave per row the
 // launch was bound by the rate at which workgroups start, not by HBM (0.28 ms for 0.46 GB).
-template <typename V>
+template <typename V, int LPR>
 __global__ __launch_bounds__(256) void spmm_listless_rows_kernel(long n_list, const int *__restrict__ rows, int nchunk,
                                                                   float *__restrict__ out, long ldo,
                                                                   const float *__restrict__ self, long ld_self, SpmmExtra ex) {
+    // LPR lanes per row (a power of two <= 64), 256 / LPR rows per workgroup; the row maximum meets inside the group (one
+    // plain store per row: nobody else writes an empty row's maximum -- an atomic per chunk cost this pass 0.3 ms at 644 k rows)
     using ops = vec_ops<V>;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_list * nchunk) return;
-    const long row = rows[idx / nchunk];
-    const int chunk = (int)(idx % nchunk);
-    V acc = ops::zero();
-    if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + row * ld_self)[chunk]);
-    if (const float *a2 = ex.add2_row(row)) ops::fma(acc, 1.f, reinterpret_cast<const V *>(a2)[chunk]);
-    reinterpret_cast<V *>(out + row * ldo)[chunk] = acc;
-    if (ex.copy_dst)
-        reinterpret_cast<V *>(ex.copy_dst + row * ex.ld_copy_dst)[chunk] =
-            reinterpret_cast<const V *>(ex.copy_src + row * ex.ld_copy_src)[chunk];
-    if (ex.rowmax) atomicMax(ex.rowmax + row, __float_as_int(ops::absmax(acc)));
+    const int sl = threadIdx.x % LPR;
+    const long r = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const bool live = r < n_list;
+    const long row = live ? rows[r] : 0;
+    float mx = 0.f;
+    if (live) {
+        const float *a2 = ex.add2_row(row);
+        for (int chunk = sl; chunk < nchunk; chunk += LPR) {
+            V acc = ops::zero();
+            if (self) ops::fma(acc, 1.f, reinterpret_cast<const V *>(self + row * ld_self)[chunk]);
+            if (a2) ops::fma(acc, 1.f, reinterpret_cast<const V *>(a2)[chunk]);
+            reinterpret_cast<V *>(out + row * ldo)[chunk] = acc;
+            if (ex.copy_dst)
+                reinterpret_cast<V *>(ex.copy_dst + row * ex.ld_copy_dst)[chunk] =
+                    reinterpret_cast<const V *>(ex.copy_src + row * ex.ld_copy_src)[chunk];
+            mx = fmaxf(mx, ops::absmax(acc));
+        }
+    }
+    if (ex.rowmax) {                       // (workgroup-uniform; every lane takes part in the group reduction)
+        mx = group_max<LPR>(mx);
+        if (live && sl == 0) ex.rowmax[row] = __float_as_int(mx);
+    }
 }
 
 template <typename V, int LPE, int U, bool FULL>
@@ -665,16 +677,25 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
                        listed ? rows_with_entries : nullptr, listed ? (int)n_rows_with_entries : 0};
     if (listed && n_rows_without_entries > 0) {      // the rows without entries: one streaming pass (all column slabs at once)
         const int nchunk_all = vec ? d / 4 : d;
-        const int64_t threads = n_rows_without_entries * nchunk_all;
-        LKG_REQUIRE((threads + 255) / 256 < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large");
-        if (vec)
-            hipLaunchKernelGGL((spmm_listless_rows_kernel<float4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
-                               (long)n_rows_without_entries, rows_without_entries, nchunk_all, out, (long)ldo, self,
-                               (long)ld_self, ex);
-        else
-            hipLaunchKernelGGL((spmm_listless_rows_kernel<float>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
-                               (long)n_rows_without_entries, rows_without_entries, nchunk_all, out, (long)ldo, self,
-                               (long)ld_self, ex);
+        const int lpr = nchunk_all <= 8 ? 8 : nchunk_all <= 16 ? 16 : nchunk_all <= 32 ? 32 : 64;
+        const int64_t blocks_e = (n_rows_without_entries + 256 / lpr - 1) / (256 / lpr);
+        LKG_REQUIRE(blocks_e < (int64_t)UINT32_MAX, "lkg_spmm_csr_f32: grid too large");
+#define LKG_LISTLESS(V_, LPR_)                                                                                          \
+    hipLaunchKernelGGL((spmm_listless_rows_kernel<V_, LPR_>), dim3((unsigned)blocks_e), dim3(256), 0, s,                \
+                       (long)n_rows_without_entries, rows_without_entries, nchunk_all, out, (long)ldo, self,            \
+                       (long)ld_self, ex)
+        if (vec) {
+            if (lpr == 8) LKG_LISTLESS(float4, 8);
+            else if (lpr == 16) LKG_LISTLESS(float4, 16);
+            else if (lpr == 32) LKG_LISTLESS(float4, 32);
+            else LKG_LISTLESS(float4, 64);
+        } else {
+            if (lpr == 8) LKG_LISTLESS(float, 8);
+            else if (lpr == 16) LKG_LISTLESS(float, 16);
+            else if (lpr == 32) LKG_LISTLESS(float, 32);
+            else LKG_LISTLESS(float, 64);
+        }
+#undef LKG_LISTLESS
         LKG_CHECK_LAUNCH("lkg_spmm_csr_f32");
         if (n_rows_with_entries == 0 && n_long == 0) return LKG_OK;
     }

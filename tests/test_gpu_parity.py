@@ -1507,9 +1507,12 @@ def test_spmm_over_mostly_empty_rows_takes_the_row_lists(L, ops, gpu_device, d):
                              copy=(x, cdst) if cdst is not None else None, rowmax=rm, **k2)
                 outs.append((out, cdst, rm))
             (o0, c0, m0), (o1, c1, m1) = outs
-            assert torch.equal(o0, o1), (d, transposed, sorted(kw))
+            if d == 32:       # (8 chunks: the unlisted launch is the eight-rows-per-wave kernel, another order of the float sums)
+                torch.testing.assert_close(o0, o1, rtol=1e-5, atol=1e-5)
+            else:
+                assert torch.equal(o0, o1), (d, transposed, sorted(kw))
             assert c0 is None or (torch.equal(c0, c1) and torch.equal(c1, x))
-            assert m0 is None or torch.equal(m0, m1)
+            assert m0 is None or (torch.allclose(m0, m1, rtol=1e-5, atol=1e-6) if d == 32 else torch.equal(m0, m1))
 
 
 def test_module_step_on_a_sparse_id_space_equals_the_unlisted_launches(L, O, gpu_device):
