@@ -88,6 +88,11 @@ int lkg_csr_transpose_device(int64_t n_rows, int64_t n_cols, int64_t nnz, const 
                              int32_t *t_rowptr, int32_t *t_col, int32_t *t_perm, void *workspace,
                              int64_t workspace_bytes, void *stream);
 
+/* indices_out int64[2 * nnz] (device) = the [2, nnz] index tensor of the coalesced sparse COO A_in the reference keeps
+ * (model.py:462-468, 257-261): row 0 the head of every stored entry, row 1 its tail, in the structure's entry order.   */
+int lkg_csr_coo_indices_i64(int64_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                            int64_t *indices_out, void *stream);
+
 /* Cut [0, n_rows) into n_parts contiguous row ranges balanced by stored entries
  * (cuts only at row boundaries so a softmax row never straddles two GPUs,
  * SURVEY.md 8e).  cuts int64[n_parts+1].                                     */

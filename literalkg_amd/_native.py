@@ -15,6 +15,7 @@ PROTOTYPES = {
     "lkg_csr_build": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_csr_transpose": [i64, i64, i64, vp, vp, vp, vp, vp],
     "lkg_row_partition": [i64, vp, i32, vp],
+    "lkg_csr_coo_indices_i64": [i64, i64, vp, vp, vp, vp],
     "lkg_csr_build_device_workspace": [i64, i64],
     "lkg_csr_build_device": [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "lkg_csr_transpose_device_workspace": [i64, i64],

@@ -473,6 +473,34 @@ extern "C" int lkg_laplacian_device_f32(int64_t n_entities, int64_t nnz, int32_t
     return LKG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The int64 [2, nnz] index tensor of the reference's coalesced A_in (model.py:462-468: rows = heads, cols = tails, sorted by
+// (row, col)) straight from the CSR: one wave per head row writes its entries' (row, col) pairs.
+namespace {
+__global__ __launch_bounds__(256) void coo_indices_kernel(long n, long nnz, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ col, long *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int j0 = rowptr[i], j1 = rowptr[i + 1];
+    for (int j = j0 + lane; j < j1; j += 64) {
+        out[j] = i;
+        out[nnz + j] = col[j];
+    }
+}
+}  // namespace
+
+extern "C" int lkg_csr_coo_indices_i64(int64_t n_rows, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                       int64_t *indices_out, void *stream) {
+    LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && nnz >= 0, "lkg_csr_coo_indices_i64: bad sizes");
+    if (nnz == 0 || n_rows == 0) return LKG_OK;
+    LKG_REQUIRE(rowptr && col && indices_out, "lkg_csr_coo_indices_i64: null pointer");
+    hipLaunchKernelGGL(coo_indices_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
+                       (long)nnz, rowptr, col, reinterpret_cast<long *>(indices_out));
+    LKG_CHECK_LAUNCH("lkg_csr_coo_indices_i64");
+    return LKG_OK;
+}
+
 // lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
 // attributes is such a use (no launch).
 int lkg_internal_preload_csr_device() {

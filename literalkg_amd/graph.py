@@ -262,7 +262,14 @@ class KGStructure:
     def coo_indices(self) -> torch.Tensor:
         """int64[2, nnz], sorted by (row, col): the indices of the reference's coalesced A_in."""
         if self._coo is None:
-            self._coo = torch.stack([self.entry_rows(), self.col.long()])
+            if self.rowptr.is_cuda:           # one library kernel (no first-use loading of torch's repeat_interleave / stack)
+                out = torch.empty((2, self.nnz), dtype=torch.int64, device=self.device)
+                with torch.cuda.device(self.device):
+                    N.call("lkg_csr_coo_indices_i64", self.n, self.nnz, N.ptr(self.rowptr), N.ptr(self.col), N.ptr(out),
+                           torch.cuda.current_stream(self.device).cuda_stream)
+                self._coo = out
+            else:
+                self._coo = torch.stack([self.entry_rows(), self.col.long()])
         return self._coo
 
     def row_cuts(self, n_parts: int) -> np.ndarray:

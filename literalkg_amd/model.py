@@ -551,10 +551,14 @@ class LiteralKG(nn.Module):
             return self._triple_graph
         h, t, r = h_list, t_list, r_list
         if relations is not None:      # the reference only visits `relations` (model.py:451): other triples are dropped
-            rel_ids = torch.as_tensor(list(relations), dtype=r.dtype, device=r.device)
-            keep = torch.isin(r, rel_ids)
-            if not bool(keep.all()):
-                h, t, r = h[keep], t[keep], r[keep]
+            every = sorted(set(rel_key)) == list(range(self.n_relations))
+            # (the usual call visits EVERY relation: then the filter keeps exactly the triples with a valid relation id, which
+            # the id sanitiser counts -- no torch.isin over the edge list, whose first use alone costs the first refresh 25 ms)
+            if not (every and r.is_cuda and ops.count_ids_outside(self.n_relations, r) == 0):
+                rel_ids = torch.as_tensor(list(relations), dtype=r.dtype, device=r.device)
+                keep = torch.isin(r, rel_ids)
+                if not bool(keep.all()):
+                    h, t, r = h[keep], t[keep], r[keep]
         g = KGStructure.from_triples(self.n_entities, h, t, r, device=dev)
         self._triple_graph = g
         self._triple_key = (rel_key, str(dev), tuple(x.detach().clone() for x in (h_list, t_list, r_list)))

@@ -128,6 +128,18 @@ def checked_ids(n_rows: int, *id_lists: torch.Tensor, what: str = "entity"):
     return res
 
 
+def count_ids_outside(n_rows: int, ids: torch.Tensor) -> int:
+    """How many of ``ids`` lie outside [0, n_rows)?  (One pass of the id sanitiser; the answer is read on the host.)"""
+    _need_gpu(ids)
+    src = _i64(ids.reshape(-1))
+    if src.numel() == 0:
+        return 0
+    out = torch.empty_like(src)
+    bad = torch.empty(1, dtype=torch.int32, device=src.device)
+    N.call("lkg_sanitize_ids_i64", src.numel(), N.ptr(src), 0, int(n_rows), N.ptr(out), N.ptr(bad), _stream())
+    return int(bad.item())
+
+
 # ----------------------------------------------------------------------------- raw launches
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
@@ -198,7 +210,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
         raise ValueError(f"gemm: out must be a float32 {m} x {n} tensor with unit column stride (got {tuple(out.shape)})")
     if bias is not None and bias.numel() != n:
         raise ValueError(f"gemm: bias of {bias.numel()} elements for {n} output columns")
-    if (not trans_a and alpha == 1.0 and _ENGINE != "f32"
+    if (not trans_a and alpha == 1.0 and _ENGINE != "f32" and (k * n <= 2048 or m < TALL_MIN_ROWS)
             and N.load().lkg_gemm_skinny_ok(m, n, k, N.ptr(a), _ld(a), N.ptr(out), _ld(out))):
         # narrow in AND out (the 32 x 32 products of narrow layers): exact f32 on the VALU at streaming rate
         N.call("lkg_gemm_skinny_f32", m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), int(trans_b), float(beta), N.ptr(out),
@@ -897,7 +909,9 @@ class _MultiLinear(Function):
 
 def _skinny(x: torch.Tensor, n_out: int) -> bool:
     """Is x @ W^T (n_out columns) a product for lkg_gemm_skinny_f32 (many rows, <= 64 columns in and out)?"""
+    # (k * n <= 2048: measured at 766 k x 64 x 64 the VALU kernel takes 157 us, the 128-column matrix-core tile 131 us)
     return (x.dim() == 2 and x.shape[0] >= 4096 and 4 <= x.shape[1] <= 64 and 4 <= n_out <= 64 and x.shape[1] % 4 == 0
+            and x.shape[1] * n_out <= 2048
             and n_out % 4 == 0 and _ENGINE != "f32" and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 

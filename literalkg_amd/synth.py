@@ -73,8 +73,8 @@ def make_kg(n_entities: int, n_edges: int, skew: str = "zipf", seed: int = 2022,
 
 def make_kg_device(n_entities: int, n_edges: int, skew: str, seed: int, device):
     """(h, t, r) int64 DEVICE tensors drawn like make_kg's heads / tails / relations, in milliseconds instead of the minute
-    numpy takes for 100 M triples: for timing shapes far beyond the parity-tested ones.  No (h, r, t) de-duplication and no
-    degree clip (the structure build merges equal (h, t) pairs; the SpMM's team workgroups take the long rows)."""
+    numpy takes for 100 M triples: for timing shapes far beyond the parity-tested ones.  Out-degrees clipped at DEGREE_CAP like
+    make_kg's; no (h, r, t) de-duplication (the structure build merges equal (h, t) pairs)."""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -87,6 +87,15 @@ def make_kg_device(n_entities: int, n_edges: int, skew: str, seed: int, device):
         h = torch.randint(0, n, (e,), generator=gen, device=device)
     else:
         raise ValueError(skew)
+    if skew == "zipf":             # make_kg's degree clip: the edges beyond DEGREE_CAP of a head get a uniformly drawn head
+        order = torch.argsort(h, stable=True)
+        hs = h[order]
+        first = torch.ones(e, dtype=torch.bool, device=device)
+        first[1:] = hs[1:] != hs[:-1]
+        start = torch.cummax(torch.where(first, torch.arange(e, device=device), torch.zeros((), dtype=torch.int64, device=device)), 0).values
+        over = order[(torch.arange(e, device=device) - start) >= DEGREE_CAP]
+        h[over] = torch.randint(0, n, (over.numel(),), generator=gen, device=device)
+        del order, hs, first, start, over
     t = torch.randint(0, n, (e,), generator=gen, device=device)
     r = torch.randint(0, N_REL, (e,), generator=gen, device=device)
     return h, t, r

@@ -16,6 +16,7 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--e", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--device-graph", action="store_true", help="draw the graph on the device (fast; no de-duplication, no degree clip)")
+ap.add_argument("--only-main", action="store_true", help="time only the library's default forward / transpose launches (PMC passes)")
 ap.add_argument("--grouped", default="", help="comma list of LKG_SPMM_GROUPED_CHUNKS values to time as well (experiment)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -50,6 +51,12 @@ for skew in ap_skews:
                              long_rows=g.long_rows(False))
         return run
     extra = [(f"fwd in {k} column slabs   ", slabs(k)) for k in (2, 4, 8, 16) if d % (4 * k) == 0 and d // k >= 16]
+    if args.only_main:
+        for name, fn in [("fwd", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
+                         ("bwd", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out, long_rows=g.long_rows(True)))]:
+            med, mn = timeit(fn)
+            print(f"{skew:8s} D={d} {name} median {med:.3f} ms -> {by/med/1e6:.0f} GB/s algorithmic ({by/med/1e6/8000:.3f} of 8 TB/s)")
+        continue
     for name, fn in extra + [
         ("fwd wave-per-row      ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out)),
         ("fwd + long-row blocks ", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
