@@ -750,6 +750,9 @@ class _AggregateKeep(Function):
         _need_gpu(ego, val)
         _check_table(ego, g, val)
         ctx.g, ctx.val_t, ctx.plus_self = g, val_t, plus_self
+        # (a leaf input -- the raw entity table of a model without a gate -- takes its gradient dense: its consumer is the
+        # optimizer, nobody would read a row set; the frontier form pays off when a gate's backward follows)
+        ctx.follow_frontier = not ego.is_leaf
         ctx.set_materialize_grads(False)
         copy = None
         kept = ego
@@ -772,7 +775,7 @@ class _AggregateKeep(Function):
         g_side = _f32_rows(g_side)
         rk = tagged_rows(g_kept)
         d = g_side.shape[1]
-        if (rows is not None and (g_kept is None or rk is not None) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0
+        if (ctx.follow_frontier and rows is not None and (g_kept is None or rk is not None) and rs.n_max * FRONTIER_GROWTH <= g.n and d % 4 == 0
                 and d <= 1024 and g_side.data_ptr() % 16 == 0 and _ld(g_side) % 4 == 0
                 and (g_kept is None or (g_kept.data_ptr() % 16 == 0 and _ld(g_kept) % 4 == 0))):
             # both gradients are zero outside a few rows (a one-layer model behind a gate: the loss's rows and what one
