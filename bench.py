@@ -334,7 +334,9 @@ def gate_timing(n, d, dev):
     flops = 2.0 * n * (d + 302) * d * 2
     alg = 4.0 * n * (d + 302 + d)
     traffic, src = None, "no PMC summary committed"
-    rec_path = os.path.join(ROOT, "profiles", "r02_gate_pmc_traffic.json")
+    import glob
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gate_pmc_traffic.json")))
+    rec_path = recs[-1] if recs else os.path.join(ROOT, "profiles", "none")
     if os.path.exists(rec_path):          # counter-measured HBM bytes of this launch, valid for THIS kernel source only
         rec = json.load(open(rec_path))
         sha = source_sha(os.path.join(ROOT, "literalkg_amd", "csrc", "lkg_gemm_tall.hip"))
