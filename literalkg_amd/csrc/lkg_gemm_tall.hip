@@ -911,8 +911,10 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
             }                                                                                                          \
             resident = std::max(8, per_cu_ * cus_ / 8 * 8);                                                            \
         }                                                                                                              \
-        /* persistent workgroups: one stripe of tiles per resident workgroup, a multiple of 8 (one per XCD) */        \
-        const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, resident));                                 \
+        /* persistent workgroups: one stripe of tiles per resident workgroup, a multiple of 8 (one per XCD);           \
+           LKG_TALL_ONE_TILE=1 (A/B switch): one workgroup per tile, as before round 3 */                              \
+        const bool one_tile_ = getenv("LKG_TALL_ONE_TILE") != nullptr;                                                 \
+        const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
         hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_>), grid, dim3(2 * BN_), lds, s, g);                       \
     } while (0)
     if (epilogue == EPI_GATE) {

@@ -28,6 +28,9 @@ for skew in ap_skews:
     else:
         h, t, r = make_kg(args.n, args.e, skew)
     g = L.KGStructure.from_triples(args.n, h, t, r, device=dev)
+    del h, t, r
+    if os.environ.get("LKG_MICRO_EMPTY_CACHE"):     # (does the allocator's reuse of the graph generator's blocks matter for the tables?)
+        torch.cuda.empty_cache()
     d = args.dim
     x = xavier_table(args.n, d, dev)
     val = torch.rand(g.nnz, device=dev)
