@@ -913,7 +913,10 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
         }                                                                                                              \
         /* persistent workgroups: one stripe of tiles per resident workgroup, a multiple of 8 (one per XCD);           \
            LKG_TALL_ONE_TILE=1 (A/B switch): one workgroup per tile, as before round 3 */                              \
-        const bool one_tile_ = getenv("LKG_TALL_ONE_TILE") != nullptr;                                                 \
+        /* several column tiles per row tile (the gate: 2): one workgroup per tile -- the workgroups of a row tile then \
+           start together and the second one finds the A windows in the L2 (1.54 x the algorithmic traffic by the fabric \
+           counters); persistent workgroups drift apart and every row tile's inputs cross the fabric twice (1.98 x) */   \
+        const bool one_tile_ = g.tiles_n > 1 || getenv("LKG_TALL_ONE_TILE") != nullptr;                                \
         const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
         hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_>), grid, dim3(2 * BN_), lds, s, g);                       \
     } while (0)
