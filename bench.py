@@ -291,13 +291,16 @@ def c4_regime_timing(d, dev, n=5_000_000, e=100_000_000):
     import literalkg_amd as L
     from literalkg_amd import ops
     from literalkg_amd.synth import make_kg_device
+    # the two 5 GB tables FIRST, as a model allocates its embeddings before any edge list arrives: allocated behind the graph
+    # generator's and the structure build's temporaries the same launches measured 10 % slower (19.2 / 18.3 ms against 17.6 /
+    # 16.7 ms in one process on one graph, tools/graph_family_check.py: placement in physical memory, not the kernel)
+    x = torch.randn((n, d), device=dev) * 0.05
+    out = torch.empty((n, d), device=dev)
     h, t, r = make_kg_device(n, e, "zipf", 2022, dev)
     g = L.KGStructure.from_triples(n, h, t, r, device=dev)
     del h, t, r
     val = torch.rand(g.nnz, device=dev)
     val_t = ops.permute_values(val, g.t_perm)
-    x = torch.randn((n, d), device=dev) * 0.05
-    out = torch.empty((n, d), device=dev)
 
     def ev_time(fn, reps=8):
         for _ in range(2):

@@ -25,7 +25,7 @@ ge.build()
 import literalkg_amd as L
 from literalkg_amd import ops
 from literalkg_amd.sharding import FeatureShardedAggregation, shard_bounds
-from literalkg_amd.synth import make_kg
+from literalkg_amd.synth import make_kg_device
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
@@ -38,14 +38,14 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 G, n, d = args.world, args.n, args.dim
 dg = d // G
-h, t, r = make_kg(n, args.e, "zipf")
+slab = torch.randn((n, dg), device=dev) * 0.05          # (the tables first, like a model's: see tools/graph_family_check.py)
+out = torch.empty((n, dg), device=dev)
+h, t, r = make_kg_device(n, args.e, "zipf", 2022, dev)
 g = L.KGStructure.from_triples(n, h, t, r, device=dev)
 del h, t, r
 val = torch.rand(g.nnz, device=dev)
 cuts = shard_bounds(g, G)
 fs = FeatureShardedAggregation(g, val, 0, G, d, cuts)
-slab = torch.randn((n, dg), device=dev) * 0.05
-out = torch.empty((n, dg), device=dev)
 by = g.nnz * (4 * dg + 8) + n * 4 * dg + 4 * (n + 1)
 
 
@@ -89,7 +89,7 @@ def bwd_parts(nb):
         for part, val_p in zip(parts, vals):
             if part is None or part.nnz == 0:
                 continue
-            ops.spmm_raw(part.t_rowptr, part.t_col, val_p, slab, n, out=out, long_rows=part.long_rows,
+            ops.spmm_raw(part.rowptr, part.col, val_p, slab, n, out=out, long_rows=part.long_rows(),
                          add2=None if first else out)
             first = False
     return run, [sum(1 for _ in b) for b in batches], [p.nnz if p is not None else 0 for p in parts]
@@ -111,7 +111,7 @@ for nb in (2, 3, 4):
     batches, parts, vals = fs.head_parts(nb)
     stage = []
     for i, (part, val_p) in enumerate(zip(parts, vals)):
-        stage.append(timeit(lambda: ops.spmm_raw(part.t_rowptr, part.t_col, val_p, slab, n, out=out, long_rows=part.long_rows,
+        stage.append(timeit(lambda: ops.spmm_raw(part.rowptr, part.col, val_p, slab, n, out=out, long_rows=part.long_rows(),
                                                  add2=None if i == 0 else out)))
     res[f"bwd_{nb}_head_parts"]["stage_ms"] = stage
 for k, v in res.items():
