@@ -416,8 +416,12 @@ class _Aggregate(Function):
         if bool((every >= 0).all()) and small:
             send = [int(c) for c in every[p.rank, :p.world]]
             recv = [int(c) for c in every[:, p.rank]]
-            got_ids = _all_to_all_rows(tails, send, recv, att.group, "frontier_ids") - p.pad_lo
-            got_rows = _all_to_all_rows(msgs, send, recv, att.group, "frontier_rows")
+            if int(every[:, :p.world].sum()) == 0:               # (every rank sees the same matrix: nobody has anything to send)
+                got_ids = torch.zeros(0, dtype=torch.int64, device=dev)
+                got_rows = torch.zeros((0, d), dtype=grad.dtype, device=dev)
+            else:
+                got_ids = _all_to_all_rows(tails, send, recv, att.group, "frontier_ids") - p.pad_lo
+                got_rows = _all_to_all_rows(msgs, send, recv, att.group, "frontier_rows")
             id_lists, row_lists = [got_ids], [got_rows]
             if ctx.plus_self:                                    # ego + side: the gradient also reaches ego's own rows F
                 id_lists.append(rows)
@@ -501,8 +505,9 @@ class ShardedLiteralKG(nn.Module):
                   text_literals=None, scoring: str = "transr", scheme: str = "features", device=None, group=None,
                   kernels=None, rank: Optional[int] = None, world: Optional[int] = None,
                   partition: Optional[str] = None, sparse_backward: str = "auto") -> "ShardedLiteralKG":
-        """partition: "rows" (equal row blocks) or "entries" (blocks balanced by the stored entries of ``A_in``: the
-        SpMM work of scheme "rows"); default: "entries" for scheme "rows" when the state holds an A_in, else "rows"."""
+        """partition: "rows" (equal row blocks), "entries" (blocks balanced by the stored entries of ``A_in``: the SpMM work of
+        scheme "rows") or an explicit list of cut points; default: "entries" for scheme "rows" when the state holds an A_in,
+        else "rows".  A rank may own no row at all (more ranks than rows, a cut that leaves a range empty)."""
         from .model import LiteralKG
         rank = dist.get_rank(group) if rank is None else rank
         world = dist.get_world_size(group) if world is None else world
@@ -510,7 +515,9 @@ class ShardedLiteralKG(nn.Module):
         has_a = a_in is not None and a_in._nnz() > 0
         if partition is None:
             partition = "entries" if (scheme == "rows" and has_a) else "rows"
-        if partition == "entries":
+        if isinstance(partition, (list, tuple)):                 # explicit cut points (world + 1 of them, ascending, 0 .. N)
+            part = RowPartition(n_entities, rank, world, partition)
+        elif partition == "entries":
             if not has_a:
                 raise ValueError("partition='entries' needs an A_in in the state_dict")
             part = RowPartition.balanced(n_entities, rank, world, a_in.coalesce().indices()[0])

@@ -40,6 +40,8 @@ class CpuKernels:
     @staticmethod
     def edge_softmax(g, ent, rel, row_lo=0, row_hi=None):
         """attention values in g's entry order, from the oracle's refresh on the raw triples of g"""
+        if g.nnz == 0:                      # (a rank without rows: nothing to refresh, as in ops.edge_softmax)
+            return torch.zeros(0)
         heads = g.entry_rows()
         eptr = g.eptr.long() if g.eptr is not None else torch.arange(g.nnz + 1)
         per_entry = eptr[1:] - eptr[:-1]

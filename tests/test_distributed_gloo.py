@@ -248,3 +248,60 @@ def test_row_partition_padded_coordinates():
     h = torch.tensor([0] * 50 + [1] * 2 + list(range(2, 40)))
     b = [RowPartition.balanced(40, r, 4, h) for r in range(4)]
     assert b[0].cuts[0] == 0 and b[0].cuts[-1] == 40 and b[0].cuts == b[3].cuts and b[0].rows < b[3].rows
+
+
+def _empty_rank_worker(rank, world, port, scheme, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import cpu_standins
+        cpu_standins.patch_ops()
+        from literalkg_amd.distributed import ShardedLiteralKG
+        from oracle import literalkg_oracle as O
+        g = load_golden("encoder_gcn_l2_scale")
+        cfg = golden_cfg(g)
+        cfg.device = torch.device("cpu")
+        n, n_rel = int(g["n"]), int(g["n_rel"])
+        state = dict(golden_params(g))
+        state["A_in"] = torch.sparse_coo_tensor(torch.from_numpy(g["a_indices"]), torch.from_numpy(g["a_values"]), (n, n)).coalesce()
+        cuts = [0, n // 2, n // 2, n]                          # the MIDDLE rank owns no row at all
+        m = ShardedLiteralKG.from_full(cfg, n, n_rel, state, scoring="transr", scheme=scheme, device="cpu",
+                                       kernels=cpu_standins.CpuKernels, partition=cuts, sparse_backward="always").train()
+        assert m.part.rows == (0 if rank == 1 else (n // 2 if rank == 0 else n - n // 2))
+        batch = [torch.from_numpy(g[k]) for k in ("bh", "br", "bp", "bn")]
+        loss = m(*batch, device=cfg.device, mode="pre_training")
+        np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+        loss.backward()
+        m.sync_gradients()                                      # the bucket has one layout on every rank, rows or no rows
+        assert _check_grads(m, g, "g/", world) >= 4
+        h, t, r = (torch.from_numpy(g[k]) for k in "htr")
+        m(h, t, r, list(range(n_rel)), device=cfg.device, mode="update_att")
+        want = O.attention_refresh(n, torch.from_numpy(g["p/entity_embed.weight"]), torch.from_numpy(g["p/relation_embed.weight"]),
+                                   h, t, r).coalesce()
+        got = m.full_state_dict()["A_in"].coalesce()
+        assert torch.equal(got.indices(), want.indices())
+        torch.testing.assert_close(got.values(), want.values(), rtol=1e-4, atol=1e-6)
+        q.put((rank, "ok"))
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-3000:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme", ["rows", "features"])
+def test_a_rank_without_rows_takes_part_in_every_collective(scheme):
+    """More ranks than row ranges worth having (world > N in the limit): a rank that owns NO entity row still runs every
+    exchange -- table gathers, frontier counts, the fixed weight-gradient bucket -- and the results are the reference's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 3, port, scheme, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [(r, msg) for r, msg in res if msg != "ok"]
+    assert not bad, bad
