@@ -75,8 +75,13 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
         const int cnt = min(64, end - base);
         const int last = cnt - 1;
         // one coalesced fetch of up to 64 (col, val) pairs; lanes past the row end copy its last entry
+#ifdef LKG_SPMM_NT        /* A/B switch: the index stream and the result are touched once -- streaming loads / stores */
+        const int c = __builtin_nontemporal_load(col + base + min(lane, last));
+        const float v = __builtin_nontemporal_load(val + base + min(lane, last));
+#else
         const int c = col[base + min(lane, last)];
         const float v = val[base + min(lane, last)];
+#endif
         for (int k = 0; k < cnt; k += EPW * U) {
             int cc[U];
             float vv[U];
@@ -297,7 +302,17 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
             if (FULL || chunk < nchunk) {
                 if (own) ops::fma(acc[i], 1.f, own[chunk]);   // out = self + A @ x  (ego + side, model.py:109)
                 if (own2) ops::fma(acc[i], 1.f, own2[chunk]);
+#ifdef LKG_SPMM_NT
+                if constexpr (std::is_same<V, float4>::value) {
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 nv = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(dst + chunk));
+                } else {
+                    __builtin_nontemporal_store(acc[i], dst + chunk);
+                }
+#else
                 dst[chunk] = acc[i];
+#endif
                 if (cdst) cdst[chunk] = csrc[chunk];
                 rmax = fmaxf(rmax, ops::absmax(acc[i]));
             }

@@ -1689,6 +1689,39 @@ def test_bench_prints_one_contract_line(gpu_device):
     assert c["kind"] in ("port", "reference") and c["value"] > 0
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,dim", [(2, 256), (4, 128)])
+def test_bench_multi_rank_path_on_one_gpu(gpu_device, world, dim):
+    """The N > 1 path of bench.py end to end (its own launcher, both sharding schemes, the pipelined exchanges -- at world 4
+    and 32 columns per rank the head-part backward of the N = 8 run --, the integrated sharded step) with all ranks on the one
+    GPU over gloo: exit code 0, one JSON line, both schemes at the top level, every spot check ok, no phase reported as failed.
+    (The numbers of such a run mean nothing; the line says so in `data`.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--rehearse-on-one-gpu", "--steps", "2",
+                          "--warmup", "1", "--entities", "30000", "--edges", "300000", "--dim", str(dim)],
+                         capture_output=True, text=True, timeout=560, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["n_ranks_seen"] == world and j["scaling"] == "weak" and "REHEARSAL" in j["data"]
+    assert j["value"] > 0 and j["value_rows"] > 0 and j["value_features"] > 0 and "rccl_version" in j
+    assert j["config"]["value_scheme"] in ("features", "rows") and j["config"]["value_scheme"] in j["config"]["workload"]
+    assert j["config"]["spot_check"] == "ok" and j["rows_scheme"]["spot_check"] == "ok"
+    fx = j["features_exchanges"]
+    assert fx["features"]["spot_check"] == "ok" and fx["features_pipelined"]["spot_check"] == "ok"
+    assert "pipelined_exchange_error" not in fx and "hung_phase" not in j
+    st = j["sharded_pre_training_step"]
+    assert "error" not in st and st["rows"]["ms_per_step"] > 0 and st["features"]["ms_per_step"] > 0
+    for scheme in ("rows", "features"):
+        sent = st[scheme]["bytes_sent_per_step_rank0"]
+        assert sent["head_rows"] > 0 and sent["weight_gradients"] > 0 and sent["aggregate_forward"] > 0
+
+
 # ----------------------------------------------------------------------------- the loss's row-sparse table gradient
 @pytest.mark.parametrize("scoring,layers,gate", [("transr", 1, None), ("transe", 2, "mul")])
 def test_loss_row_scratch_equals_a_fresh_zero_table(L, ops, O, gpu_device, scoring, layers, gate):
