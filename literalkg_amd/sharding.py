@@ -110,11 +110,16 @@ class FeatureShardedAggregation:
                                             what leaves for / arrives from the other ranks, one panel per peer.
 
     The two exchanges of a pass are pipelined with the SpMM from both ends (``exchange_aggregate``):
-      * IN  (row block -> column slab): the panels leave in BATCHES of peer offsets, all batches queued at once; the SpMM
-        runs part by part -- part b = the entries that gather from the rows of batch b (``KGStructure.structure_parts``),
-        accumulating onto the parts before it -- so the SpMM of part b runs while batch b + 1 is on the links;
-      * OUT (column slab -> row block): the LAST part runs owner range by owner range, every finished range leaves
-        point-to-point while the next one is computed.
+      * IN  (row block -> column slab): xGMI is a point-to-point mesh, one link per peer, so the exchange lasts as long as
+        ONE block on ONE link however the peers are grouped; what pipelines is a cut of every block into row sub-ranges.
+        Batch q moves sub-range q of all G - 1 incoming blocks at once (all links busy; all batches queued up front), and
+        the SpMM runs part by part -- part 0 = the entries that gather from the rank's OWN block (nothing to wait for),
+        part q + 1 = those that gather from sub-range q of the other blocks (``KGStructure.structure_parts``), each
+        accumulating onto the parts before it -- so part q + 1 runs while batch q + 1 is on the links;
+      * OUT (column slab -> row block): the LAST part runs owner range by owner range, the other ranks' rows first (each
+        range in `pieces` pieces, piece-major: all links busy from the first round on), every finished piece leaving
+        point-to-point while the next one is computed, and the rank's own rows last: the final remote piece (1 / pieces of
+        a block on its link) travels behind 1 / G of the pass.
     """
 
     def __init__(self, graph: KGStructure, val: torch.Tensor, rank: int, world: int, d: int, cuts: List[int],
@@ -150,46 +155,45 @@ class FeatureShardedAggregation:
         for key, (parts, _) in list(self._parts.items()):
             self._parts[key] = (parts, [self.permute(val, p.perm) for p in parts])
 
-    # ------------------------------------------------------------------ parts of the structure by source block
-    @staticmethod
-    def offset_batches(world: int, n_batches: Optional[int] = None) -> List[List[int]]:
-        """Peer offsets k = 0 .. G-1 (the block of rank (r - k) % G arrives at rank r; k = 0 is r's own block) grouped
-        into the batches of the part-wise SpMM.  Every rank sends and receives exactly one block per offset, so every
-        batch loads all links alike.  Batch 0 = the own block + the first peer (the SpMM starts after 1/(G-1) of the
-        exchange); the other offsets in equal groups."""
-        if n_batches is None:
-            n_batches = 1 if world < 3 else 3
-        n_batches = max(1, min(n_batches, world))
-        if n_batches == 1:
-            return [list(range(world))]
-        first = [0, 1] if world > n_batches else [0]
-        rest = list(range(len(first), world))
-        per = [len(rest) // (n_batches - 1) + (1 if i >= (n_batches - 1) - len(rest) % (n_batches - 1) else 0)
-               for i in range(n_batches - 1)]
-        out, o = [first], 0
-        for c in per:
-            out.append(rest[o:o + c])
-            o += c
-        return [b for b in out if b]
+    # ------------------------------------------------------------------ parts of the structure by source rows
+    def chunk_bounds(self, n_chunks: int) -> List[List[int]]:
+        """[i][q] .. [i][q + 1]: row sub-range q of rank i's block (global rows), n_chunks of them per block."""
+        out = []
+        for i in range(self.world):
+            lo, n = self.cuts[i], self.rows[i]
+            out.append([lo + n * q // n_chunks for q in range(n_chunks + 1)])
+        return out
 
-    def parts(self, transposed: bool, n_batches: Optional[int] = None):
-        """(offset batches, one StructurePart per batch, its values): the CSR (transposed: the CSC) cut by the block its
-        entries gather from; built once per (direction, batching) and kept."""
-        batches = self.offset_batches(self.world, n_batches)
-        key = (bool(transposed), tuple(tuple(b) for b in batches))
+    @staticmethod
+    def default_chunks(world: int) -> int:
+        """Batches of the incoming exchange: xGMI is a point-to-point mesh, ONE link per peer, so the exchange takes the time
+        of one block over one link whatever the grouping by PEER -- what pipelines is a cut of EVERY peer's block into row
+        sub-ranges: batch q moves sub-range q of all G - 1 blocks at once (all links busy, 1 / n_chunks of the time each)."""
+        return 1 if world < 2 else 3
+
+    def parts(self, transposed: bool, n_chunks: Optional[int] = None):
+        """(n_chunks, StructureParts, their values): the CSR (transposed: the CSC) cut by the ROWS its entries gather from --
+        part 0 = the rank's own block (no transfer), part q + 1 = row sub-range q of every other rank's block; built once
+        per (direction, n_chunks) and kept."""
+        n_chunks = self.default_chunks(self.world) if n_chunks is None else max(1, int(n_chunks))
+        key = (bool(transposed), n_chunks)
         if key not in self._parts:
-            part_of_block = [0] * self.world
-            for b, ks in enumerate(batches):
-                for k in ks:
-                    part_of_block[(self.rank - k) % self.world] = b
-            parts = self.graph.structure_parts(transposed, self.cuts, part_of_block)
-            assert len(parts) == len(batches)
+            bounds = self.chunk_bounds(n_chunks)
+            cuts, part_of = [0], []
+            for i in range(self.world):
+                for q in range(n_chunks):
+                    cuts.append(bounds[i][q + 1])
+                    part_of.append(0 if i == self.rank else q + 1)
+            parts = self.graph.structure_parts(transposed, cuts, part_of)
+            while len(parts) < n_chunks + 1:          # (one rank: no remote part at all)
+                parts.append(None)
+            parts = [p for p in parts if p is not None]
             self._parts[key] = (parts, [self.permute(self.val, p.perm) for p in parts])
         parts, vals = self._parts[key]
-        return batches, parts, vals
+        return n_chunks, parts, vals
 
-    def head_parts(self, n_batches: Optional[int] = None):
-        return self.parts(True, n_batches)
+    def head_parts(self, n_chunks: Optional[int] = None):
+        return self.parts(True, n_chunks)
 
     # ------------------------------------------------------------------ the SpMM alone (no communication)
     def column_slab(self, table: torch.Tensor) -> torch.Tensor:
@@ -216,7 +220,8 @@ class FeatureShardedAggregation:
                            side_slab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """side = A x (transposed: A^T x) on this rank's columns with both layout exchanges folded in.
           input   ``slab`` [N, D/G] (already a column slab: one whole-structure pass), or ``block_in`` [G, rows_r, D/G]
-                  (this rank's rows as panels: they leave in offset batches and the SpMM runs part by part behind them);
+                  (this rank's rows as panels: they leave in n_batches row sub-ranges and the SpMM runs part by part behind
+                  them);
           output  exchange_out: (side_slab, row block [G, rows_r, D/G]) -- the last part leaves owner range by owner range
                   (each range in ``pieces`` pieces); otherwise side_slab [N, D/G] alone.
         plus_self: side = x + A x (the layer's ``ego + side``, model.py:109)."""
@@ -229,27 +234,29 @@ class FeatureShardedAggregation:
         if block_in is not None and G > 1:
             if tuple(block_in.shape) != (G, self.my_rows, dg) or not block_in.is_contiguous():
                 raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected a contiguous {(G, self.my_rows, dg)}")
-            batches, parts, vals = self.parts(transposed, n_batches)
+            n_chunks, parts, vals = self.parts(transposed, n_batches)
+            bounds = self.chunk_bounds(n_chunks)
             slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
-            slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # offset 0: no transfer
+            slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # the own block: no transfer
             staged = self._staged(block_in)
-            queued = []
-            for ks in batches:               # ALL batches are queued now, in order, on the collective library's stream
+            queued = [([], [])]              # (part 0 = the own block waits for nothing)
+            for q in range(n_chunks):        # ALL batches are queued now, in order, on the collective library's stream
                 ops_, host = [], []
-                for k in ks:
-                    if k == 0:
-                        continue
+                mlo, mhi = bounds[r][q] - self.cuts[r], bounds[r][q + 1] - self.cuts[r]      # sub-range q of MY rows
+                for k in range(1, G):
                     j, i = (r + k) % G, (r - k) % G
-                    if self.my_rows:
-                        ops_.append(dist.P2POp(dist.isend, block_in[j].cpu() if staged else block_in[j], j, self.group))
-                        self.bytes_sent += block_in[j].numel() * block_in.element_size()
-                    if self.rows[i]:
-                        dst = slab[self.cuts[i]:self.cuts[i + 1]]
+                    if mhi > mlo:
+                        piece = block_in[j, mlo:mhi]
+                        ops_.append(dist.P2POp(dist.isend, piece.cpu() if staged else piece, j, self.group))
+                        self.bytes_sent += piece.numel() * block_in.element_size()
+                    if bounds[i][q + 1] > bounds[i][q]:
+                        dst = slab[bounds[i][q]:bounds[i][q + 1]]
                         rcv = torch.empty(dst.shape, dtype=dtype) if staged else dst
                         if staged:
                             host.append((rcv, dst))
                         ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
                 queued.append((dist.batch_isend_irecv(ops_) if ops_ else [], host))
+            assert len(queued) == len(parts)
         else:
             if block_in is not None:         # one rank: the row block IS the slab
                 slab = block_in[0]
@@ -325,37 +332,39 @@ class FeatureShardedAggregation:
             for st in streams:
                 st.wait_stream(main)
         works, host, step = [], [], 0
-        for p in range(pieces):
-            for k in range(G):
-                j, i = (r + k) % G, (r - k) % G
-                lo, hi = piece(self.cuts[j], self.cuts[j + 1], p)
-                ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
-                step += 1
-                with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this piece
-                    if hi > lo:
-                        self.spmm(part.rowptr[lo:hi + 1], part.col, val_p, slab, hi - lo, out=side_slab[lo:hi],
-                                  long_rows=part.long_rows(lo, hi),
-                                  add_self=add_self[lo:hi] if add_self is not None else None,
-                                  add2=None if first else side_slab[lo:hi])
-                    if k == 0:
-                        mlo, mhi = piece(0, self.my_rows, p)
-                        out[r, mlo:mhi].copy_(side_slab[lo:hi])
-                        continue
-                    rlo, rhi = piece(0, self.my_rows, p)          # the matching piece of MY rows, arriving from rank i
-                    ops_ = []
-                    if hi > lo:
-                        snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
-                        ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
-                        self.bytes_sent += (hi - lo) * dg * side_slab.element_size()
-                    if rhi > rlo:
-                        if staged:
-                            rcv = torch.empty((rhi - rlo, dg), dtype=out.dtype)
-                            host.append((rcv, i, rlo, rhi))
-                        else:
-                            rcv = out[i, rlo:rhi]
-                        ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
-                    if ops_:
-                        works += dist.batch_isend_irecv(ops_)
+        # the OTHER ranks' rows first, piece-major (all links busy from the first round on); this rank's own rows LAST, in one
+        # launch: they need no transfer, so the last remote piece (1 / pieces of a block: X / pieces on its link) travels
+        # behind 1 / G of the pass instead of behind nothing
+        order = [(p_, k_) for p_ in range(pieces) for k_ in range(1, G)] + [(None, 0)]
+        for p, k in order:
+            j, i = (r + k) % G, (r - k) % G
+            lo, hi = (self.cuts[j], self.cuts[j + 1]) if p is None else piece(self.cuts[j], self.cuts[j + 1], p)
+            ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
+            step += 1
+            with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this piece
+                if hi > lo:
+                    self.spmm(part.rowptr[lo:hi + 1], part.col, val_p, slab, hi - lo, out=side_slab[lo:hi],
+                              long_rows=part.long_rows(lo, hi),
+                              add_self=add_self[lo:hi] if add_self is not None else None,
+                              add2=None if first else side_slab[lo:hi])
+                if k == 0:
+                    out[r].copy_(side_slab[lo:hi])
+                    continue
+                rlo, rhi = piece(0, self.my_rows, p)          # the matching piece of MY rows, arriving from rank i
+                ops_ = []
+                if hi > lo:
+                    snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
+                    ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
+                    self.bytes_sent += (hi - lo) * dg * side_slab.element_size()
+                if rhi > rlo:
+                    if staged:
+                        rcv = torch.empty((rhi - rlo, dg), dtype=out.dtype)
+                        host.append((rcv, i, rlo, rhi))
+                    else:
+                        rcv = out[i, rlo:rhi]
+                    ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
+                if ops_:
+                    works += dist.batch_isend_irecv(ops_)
         if streams:
             for st in streams:
                 main.wait_stream(st)
@@ -417,14 +426,13 @@ class FeatureShardedAggregation:
     def backward_in_head_parts(self, block: torch.Tensor, out: Optional[torch.Tensor] = None,
                                n_batches: Optional[int] = None) -> torch.Tensor:
         """to_column_slab() fused with backward() when the slab is too narrow to cut by columns (N = 8: D/G = 32).
-        A^T g = sum_b A_b^T g, A_b = the entries whose HEAD lies in the row blocks of offset batch b: the blocks leave in
-        batches (point-to-point, every batch loads all links alike, all of them queued at once on the collective's
-        stream), and the transpose SpMM of part b -- a launch of the same kernel over the sub-CSC of part b, accumulating
-        onto the sum of the parts before it (``add2``) -- runs while batch b + 1 is on the links.  Exposed: the first
-        batch (one peer block) instead of the whole exchange; price: one more read of the N x D/G result per extra
-        part.  Returns grad_ego[:, my columns]."""
-        if n_batches is None and self.world >= 3:
-            n_batches = 3
+        A^T g = sum_p A_p^T g: part 0 = the entries whose HEAD lies in this rank's own rows (the SpMM starts at once),
+        part q + 1 = those whose head lies in row sub-range q of the other ranks' blocks; the blocks arrive sub-range by
+        sub-range (every batch uses all links; all batches queued at once on the collective's stream) and the transpose
+        SpMM of part q + 1 -- a launch of the same kernel over the sub-CSC of the part, accumulating onto the sum of the
+        parts before it (``add2``) -- runs while batch q + 1 is on the links.  Exposed: what the own-block part does not
+        cover of the first batch (1 / n_chunks of the exchange); price: one more read + write of the N x D/G result per
+        extra part.  Returns grad_ego[:, my columns]."""
         return self.exchange_aggregate(True, block_in=block, exchange_out=False, n_batches=n_batches, side_slab=out)
 
     # ------------------------------------------------------------------ the plain exchanges

@@ -102,16 +102,19 @@ def _feature_worker(rank, world, port, n, d, q):
         for pieces in (None, 2, 3):                                    # exchange in column pieces, SpMM per piece
             gego2 = fs.backward_from_row_block(gblock, pieces=pieces)
             ok &= torch.allclose(gego2, gego, rtol=1e-6, atol=1e-6)
-        # exchange in head-range batches, the transpose SpMM part by part behind them (the N = 8 form: D/G too narrow to
-        # cut by columns) -- the parts partition the CSC's entries, every batch moves one block per offset
-        for nb in (None, 1, 2, 3, world):
+        # exchange in row sub-ranges of every block (every batch uses every link), the transpose SpMM part by part behind
+        # them (the N = 8 form: D/G too narrow to cut by columns) -- the parts partition the CSC's entries: part 0 gathers from
+        # this rank's own rows, part q + 1 from sub-range q of the others'
+        for nb in (None, 1, 2, 3, 5):
             before = fs.bytes_sent
             gego3 = fs.backward_in_head_parts(gblock, n_batches=nb)
             ok &= torch.allclose(gego3, gego, rtol=1e-5, atol=1e-5)
             ok &= fs.bytes_sent - before == 4 * fs.dg * (hi - lo) * (world - 1)       # my rows, once to every peer
-            batches, parts, vals = fs.head_parts(nb)
-            ok &= sorted(k for b in batches for k in b) == list(range(world))
-            ok &= sum(p.nnz for p in parts if p is not None) == g.nnz
+            n_chunks, parts, vals = fs.head_parts(nb)
+            ok &= n_chunks == (3 if nb is None else nb) and len(parts) == n_chunks + 1
+            ok &= sum(p.nnz for p in parts) == g.nnz
+            heads_of_part0 = parts[0].col.long()
+            ok &= bool(((heads_of_part0 >= lo) & (heads_of_part0 < hi)).all())          # part 0: my own block only
         # both exchanges folded into the pass (the integrated step's aggregation): my rows in as panels, my rows out
         for transposed, src in ((False, x), (True, gside)):
             blk_in = torch.stack([src[lo:hi, i * fs.dg:(i + 1) * fs.dg] for i in range(world)]).contiguous()

@@ -7,8 +7,9 @@ Rank 0 of `world`: the whole structure, D / world columns.  Timed (median of --i
   fwd pipelined           the same in world x 4 head-row-range launches on two alternating streams (the launches
                           FeatureShardedAggregation.forward_to_row_block interleaves with its sends)
   bwd 1 launch            the transpose SpMM over the whole CSC
-  bwd in P head parts     FeatureShardedAggregation.backward_in_head_parts without the transfers: P launches over the
-                          sub-CSCs of the offset batches, each accumulating onto the parts before it
+  bwd in 1 + P parts      FeatureShardedAggregation.backward_in_head_parts without the transfers: the own-block part, then P
+                          launches over the sub-CSCs of row sub-range q of the other blocks, each accumulating onto the parts
+                          before it (the stage lengths of the pipeline)
 """
 import argparse
 import json
@@ -70,19 +71,19 @@ def fwd_pipelined(pieces=4):
     for st in streams:
         st.wait_stream(main)
     step = 0
-    for p in range(pieces):
-        for k in range(G):
-            lo0, hi0 = cuts[k], cuts[k + 1]
-            lo, hi = lo0 + (hi0 - lo0) * p // pieces, lo0 + (hi0 - lo0) * (p + 1) // pieces
-            with torch.cuda.stream(streams[step % 2]):
-                ops.spmm_raw(g.rowptr[lo:hi + 1], g.col, val, slab, hi - lo, out=out[lo:hi], long_rows=g.long_rows(False, lo, hi))
-            step += 1
+    order = [(p, k) for p in range(pieces) for k in range(1, G)] + [(None, 0)]      # the library's order: own rows last, one launch
+    for p, k in order:
+        lo0, hi0 = cuts[k], cuts[k + 1]
+        lo, hi = (lo0, hi0) if p is None else (lo0 + (hi0 - lo0) * p // pieces, lo0 + (hi0 - lo0) * (p + 1) // pieces)
+        with torch.cuda.stream(streams[step % 2]):
+            ops.spmm_raw(g.rowptr[lo:hi + 1], g.col, val, slab, hi - lo, out=out[lo:hi], long_rows=g.long_rows(False, lo, hi))
+        step += 1
     for st in streams:
         main.wait_stream(st)
 
 
 def bwd_parts(nb):
-    batches, parts, vals = fs.head_parts(nb)
+    n_chunks, parts, vals = fs.head_parts(nb)
 
     def run():
         first = True
@@ -92,7 +93,7 @@ def bwd_parts(nb):
             ops.spmm_raw(part.rowptr, part.col, val_p, slab, n, out=out, long_rows=part.long_rows(),
                          add2=None if first else out)
             first = False
-    return run, [sum(1 for _ in b) for b in batches], [p.nnz if p is not None else 0 for p in parts]
+    return run, n_chunks, [p.nnz if p is not None else 0 for p in parts]
 
 
 res = {"world": G, "entities": n, "stored_entries": g.nnz, "columns_per_rank": dg, "algorithmic_bytes_per_pass": by}
@@ -100,15 +101,16 @@ res["fwd_1_launch_ms"] = timeit(lambda: fs.forward(slab, out=out))
 res["fwd_pipelined_launches_ms"] = timeit(fwd_pipelined)
 res["bwd_1_launch_ms"] = timeit(lambda: fs.backward(slab, out=out))
 want = fs.backward(slab).clone()
-for nb in (2, 3, 4):
+for nb in (2, 3, 4):      # row sub-ranges per block: 1 + nb parts
     run, sizes, nnzs = bwd_parts(nb)
     ms = timeit(run)
     run()
     err = float((out - want).abs().max() / want.abs().max())
     res[f"bwd_{nb}_head_parts_ms"] = ms
-    res[f"bwd_{nb}_head_parts"] = {"offsets_per_batch": sizes, "entries_per_part": nnzs, "max_rel_err_vs_1_launch": err}
+    res[f"bwd_{nb}_head_parts"] = {"row_sub_ranges_per_block": sizes, "entries_per_part (own block first)": nnzs,
+                                   "max_rel_err_vs_1_launch": err}
     # per-part launch times (the pipeline's stage lengths)
-    batches, parts, vals = fs.head_parts(nb)
+    _, parts, vals = fs.head_parts(nb)
     stage = []
     for i, (part, val_p) in enumerate(zip(parts, vals)):
         stage.append(timeit(lambda: ops.spmm_raw(part.rowptr, part.col, val_p, slab, n, out=out, long_rows=part.long_rows(),
