@@ -48,8 +48,9 @@ val = torch.rand(g.nnz, device=dev)
 cuts = shard_bounds(g, G)
 fs = FeatureShardedAggregation(g, val, 0, G, d, cuts)
 rows0 = fs.my_rows
-block = torch.randn((G, rows0, dg), device=dev) * 0.05          # what this rank would send / receive as panels
-landing = torch.empty((G, rows0, dg), device=dev)
+rows_max = max(fs.rows)
+block = torch.randn((G, rows_max, dg), device=dev) * 0.05       # what this rank would send / receive as panels (blocks are cut
+landing = torch.empty((G, rows_max, dg), device=dev)            # by stored entries: their row counts differ a little)
 block_bytes = rows0 * dg * 4
 
 # cycles per millisecond of torch.cuda._sleep
@@ -109,11 +110,11 @@ def backward(link_ms_per_block):
             hold(link_ms_per_block / n_chunks)
             for i in range(1, G):
                 lo, hi = bounds[i][q], bounds[i][q + 1]
-                slab[lo:hi].copy_(block[i, lo - cuts[i]:hi - cuts[i]])
+                slab[lo:hi].copy_(block[i, :hi - lo])
             e = torch.cuda.Event()
             e.record()
             arrived.append(e)
-    slab[cuts[0]:cuts[1]].copy_(block[0])
+    slab[cuts[0]:cuts[1]].copy_(block[0, :rows0])
     first = True
     for b, (part, val_p) in enumerate(zip(parts, vals)):
         if b > 0:
