@@ -332,29 +332,31 @@ class FeatureShardedAggregation:
             for st in streams:
                 st.wait_stream(main)
         works, host, step = [], [], 0
-        # the OTHER ranks' rows first, piece-major (all links busy from the first round on); this rank's own rows LAST, in one
-        # launch: they need no transfer, so the last remote piece (1 / pieces of a block: X / pieces on its link) travels
-        # behind 1 / G of the pass instead of behind nothing
-        order = [(p_, k_) for p_ in range(pieces) for k_ in range(1, G)] + [(None, 0)]
-        for p, k in order:
-            j, i = (r + k) % G, (r - k) % G
-            lo, hi = (self.cuts[j], self.cuts[j + 1]) if p is None else piece(self.cuts[j], self.cuts[j + 1], p)
+
+        def launch(lo, hi):
+            nonlocal step
             ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
             step += 1
-            with ctx:      # the collective library orders its transfer behind the CURRENT stream, i.e. this piece
+            with ctx:
                 if hi > lo:
                     self.spmm(part.rowptr[lo:hi + 1], part.col, val_p, slab, hi - lo, out=side_slab[lo:hi],
-                              long_rows=part.long_rows(lo, hi),
-                              add_self=add_self[lo:hi] if add_self is not None else None,
+                              long_rows=part.long_rows(lo, hi), add_self=add_self[lo:hi] if add_self is not None else None,
                               add2=None if first else side_slab[lo:hi])
-                if k == 0:
-                    out[r].copy_(side_slab[lo:hi])
-                    continue
-                rlo, rhi = piece(0, self.my_rows, p)          # the matching piece of MY rows, arriving from rank i
-                ops_ = []
+
+        # The OTHER ranks' rows first, in `pieces` rounds: round p computes piece p of every other rank's range and then hands
+        # the round's G - 1 sends and receives to the collective library in ONE group (all links busy; 4 groups per pass
+        # instead of 28: the host has to stay ahead of 2.3 ms of launches).  This rank's own rows LAST, in one launch: they need
+        # no transfer, so the last round (1 / pieces of a block per link) travels behind 1 / G of the pass instead of nothing.
+        for p in range(pieces):
+            ops_ = []
+            for k in range(1, G):
+                j, i = (r + k) % G, (r - k) % G
+                lo, hi = piece(self.cuts[j], self.cuts[j + 1], p)
+                launch(lo, hi)
+                rlo, rhi = piece(0, self.my_rows, p)              # the matching piece of MY rows, arriving from rank i
                 if hi > lo:
-                    snd = side_slab[lo:hi].cpu() if staged else side_slab[lo:hi]
-                    ops_.append(dist.P2POp(dist.isend, snd, j, self.group))
+                    snd = side_slab[lo:hi]
+                    ops_.append((dist.isend, snd, j))
                     self.bytes_sent += (hi - lo) * dg * side_slab.element_size()
                 if rhi > rlo:
                     if staged:
@@ -362,9 +364,19 @@ class FeatureShardedAggregation:
                         host.append((rcv, i, rlo, rhi))
                     else:
                         rcv = out[i, rlo:rhi]
-                    ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
-                if ops_:
-                    works += dist.batch_isend_irecv(ops_)
+                    ops_.append((dist.irecv, rcv, i))
+            if not ops_:
+                continue
+            if streams:                       # the round's pieces sit on both compute streams: the group goes behind both
+                streams[0].wait_stream(streams[1])
+            ctx = torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()
+            with ctx:          # the collective library orders its transfers behind the CURRENT stream, i.e. this round
+                works += dist.batch_isend_irecv([dist.P2POp(fn, (t_.cpu() if (staged and fn is dist.isend) else t_), peer, self.group)
+                                                 for fn, t_, peer in ops_])
+        launch(self.cuts[r], self.cuts[r + 1])
+        ctx = torch.cuda.stream(streams[(step - 1) % len(streams)]) if streams else contextlib.nullcontext()
+        with ctx:
+            out[r].copy_(side_slab[self.cuts[r]:self.cuts[r + 1]])
         if streams:
             for st in streams:
                 main.wait_stream(st)

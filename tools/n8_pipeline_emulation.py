@@ -2,7 +2,7 @@
 """The N = 8 step of the feature-sharded aggregation on ONE GPU with the transfers EMULATED: the real per-rank launches in the
 library's order (FeatureShardedAggregation.exchange_aggregate: forward = the pass by owner ranges, other ranks' rows first;
 backward = the own-block part, then one part per row sub-range of the incoming blocks) and, in place of RCCL over xGMI, one
-stream per link that holds every message for bytes / link-rate (torch.cuda._sleep) and then moves the same bytes through HBM.
+timeline that holds every message for bytes / link-rate (torch.cuda._sleep) while writing the same bytes into HBM.
 What this checks on hardware: that the stream / event choreography overlaps as DESIGN.md section 6.1 assumes and what the
 launches cost when they run next to incoming traffic.  What it cannot check: RCCL itself (ordering of batched point-to-point
 groups, how close a link gets to its rate) -- no multi-GPU machine was available.
@@ -51,6 +51,7 @@ rows0 = fs.my_rows
 rows_max = max(fs.rows)
 block = torch.randn((G, rows_max, dg), device=dev) * 0.05       # what this rank would send / receive as panels (blocks are cut
 landing = torch.empty((G, rows_max, dg), device=dev)            # by stored entries: their row counts differ a little)
+landing_flat = landing.view(-1)
 block_bytes = rows0 * dg * 4
 
 # cycles per millisecond of torch.cuda._sleep
@@ -72,11 +73,25 @@ def hold(ms):
     torch.cuda._sleep(int(ms * cyc_per_ms))
 
 
+SUB = 6
+
+
+def arrive(ms, nbytes):
+    """`nbytes` arriving over `ms`: the time in SUB holds, after each of them that share of the bytes WRITTEN into HBM (what a
+    receive does to the memory system: writes at the links' rate, spread over the transfer -- a device copy at the end would read
+    AND write them in a burst at HBM speed and overstate the interference)"""
+    words = int(nbytes / 4 / SUB)
+    for _ in range(SUB):
+        hold(ms / SUB)
+        if words:
+            landing_flat[:words].fill_(0.5)
+
+
 def forward(link_ms_per_block):
     """the pass by owner ranges (the library's order and streams).  The links are symmetric and independent, so ONE timeline
     stands for them -- the link of the peer served LAST in every round (offset G - 1), whose pieces become ready latest: its
-    piece p is held for a quarter of a block's time once the launch that produced it is done, and when it ends the bytes of the
-    whole round (the pieces arriving over all G - 1 links) go through HBM.  (An event + a hold + a copy per piece and link --
+    piece p is held for a quarter of a block's time once the launch that produced it is done, while the bytes of the whole round
+    (the pieces arriving over all G - 1 links) are written into HBM.  (An event + a hold + a copy per piece and link --
     100 host calls per pass -- made the emulation host-bound: 3.0 ms for the 2.3 ms of launches.)"""
     for st in compute + [links[G - 1]]:
         st.wait_stream(main)
@@ -92,10 +107,8 @@ def forward(link_ms_per_block):
         if k != G - 1:
             continue
         links[G - 1].wait_stream(cs)                             # (the piece is done: the stream's work so far)
-        with torch.cuda.stream(links[G - 1]):
-            hold(link_ms_per_block / args.pieces)
-            rl, rh = rows0 * p // args.pieces, rows0 * (p + 1) // args.pieces
-            landing[1:, rl:rh].copy_(block[1:, rl:rh])           # round p's pieces from all G - 1 peers: the same bytes into HBM
+        with torch.cuda.stream(links[G - 1]):                    # round p's pieces from all G - 1 peers
+            arrive(link_ms_per_block / args.pieces, (G - 1) * block_bytes / args.pieces)
     for st in compute + [links[G - 1]]:
         main.wait_stream(st)
 
@@ -108,10 +121,7 @@ def backward(link_ms_per_block):
     arrived = []
     with torch.cuda.stream(links[1]):                            # all links run in parallel: one timeline stands for them
         for q in range(n_chunks):
-            hold(link_ms_per_block / n_chunks)
-            for i in range(1, G):
-                lo, hi = bounds[i][q], bounds[i][q + 1]
-                slab[lo:hi].copy_(block[i, :hi - lo])
+            arrive(link_ms_per_block / n_chunks, (G - 1) * block_bytes / n_chunks)
             e = torch.cuda.Event()
             e.record()
             arrived.append(e)
