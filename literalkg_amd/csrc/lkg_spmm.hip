@@ -75,7 +75,10 @@ __device__ __forceinline__ void accumulate_entries(V (&acc)[CPL], int start, int
         const int cnt = min(64, end - base);
         const int last = cnt - 1;
         // one coalesced fetch of up to 64 (col, val) pairs; lanes past the row end copy its last entry
-#ifdef LKG_SPMM_NT        /* A/B switch: the index stream and the result are touched once -- streaming loads / stores */
+        // the index stream is touched once: streaming (nontemporal) loads keep it from displacing gathered rows in the L2
+        // (with the result's streaming stores: forward 1.519 -> 1.508 ms at 1 M x 256, transpose 2.14 -> 2.10 ms at the N = 8
+        // per-rank shape; -DLKG_SPMM_PLAIN restores plain accesses for A/B runs)
+#ifndef LKG_SPMM_PLAIN
         const int c = __builtin_nontemporal_load(col + base + min(lane, last));
         const float v = __builtin_nontemporal_load(val + base + min(lane, last));
 #else
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, int nchunk,
             if (FULL || chunk < nchunk) {
                 if (own) ops::fma(acc[i], 1.f, own[chunk]);   // out = self + A @ x  (ego + side, model.py:109)
                 if (own2) ops::fma(acc[i], 1.f, own2[chunk]);
-#ifdef LKG_SPMM_NT
+#ifndef LKG_SPMM_PLAIN
                 if constexpr (std::is_same<V, float4>::value) {
                     typedef float nt4 __attribute__((ext_vector_type(4)));
                     const nt4 nv = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};

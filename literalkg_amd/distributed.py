@@ -16,9 +16,10 @@ Only the aggregation ``A_in @ ego`` needs other ranks' rows.  FORWARD, two excha
   scheme "rows"      (the north star's edge-range sharding) all-gather of the layer input (N x D), SpMM over the rank's
                      head rows.
   scheme "features"  row block -> column slab (N x D/G), SpMM over the WHOLE graph on the rank's columns, column slab ->
-                     row block; both exchanges pipelined with the SpMM (sharding.FeatureShardedAggregation: the input
-                     arrives in peer batches and the SpMM runs part by part behind them, the last part leaves owner range
-                     by owner range).  8x less traffic than gathering N x D tables at G = 8.
+                     row block; both exchanges pipelined with the SpMM (sharding.FeatureShardedAggregation: every incoming
+                     block arrives in row sub-ranges and the SpMM runs part by part behind them, the last part leaves
+                     owner range by owner range, this rank's own rows last).  8x less traffic than gathering N x D tables at
+                     G = 8.
 
 BACKWARD, chosen per call by all ranks together (one tiny all-gather of message counts):
 
