@@ -53,13 +53,18 @@ def pmc_traffic(by, skew="zipf"):
     counters cannot be read from inside the process).  Reported only when that summary was taken on THIS kernel
     source (sha of lkg_spmm.hip stored in the summary) and on this workload; otherwise null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+                   if "_gate_" not in os.path.basename(f))              # (the gate kernel's summaries are read further down)
     if not files:
         return None, "no PMC summary committed"
-    rec = json.load(open(files[-1]))
-    name = os.path.relpath(files[-1], ROOT)
-    if rec.get("spmm_source_sha16") != source_sha():
-        return None, f"{name} was taken on another lkg_spmm.hip ({rec.get('spmm_source_sha16')} != {source_sha()})"
+    recs = [(f, json.load(open(f))) for f in files]
+    match = [fr for fr in recs if fr[1].get("spmm_source_sha16") == source_sha()]
+    if not match:
+        f, rec = recs[-1]
+        return None, (f"{os.path.relpath(f, ROOT)} was taken on another lkg_spmm.hip "
+                      f"({rec.get('spmm_source_sha16')} != {source_sha()})")
+    path, rec = match[-1]
+    name = os.path.relpath(path, ROOT)
     tr = rec.get("traffic_bytes_fwd")
     # (the summaries are taken on bench.py's default workload: zipf heads unless the record says otherwise)
     if tr is None or abs(tr - by) > 0.25 * by or rec.get("skew", "zipf") != skew:      # different shape: not comparable
