@@ -209,14 +209,17 @@ int lkg_spmm_csr_scatter_bwd_f32(int64_t n_rows, int32_t d, const int32_t *rowpt
  * pre-softmax logits, val_out the attention values, both float[nnz].
  * row_offset: rowptr holds n_rows+1 offsets for head rows row_offset..row_offset+n_rows
  * (a row-range shard of a larger graph; ent always holds the full table).
- * long_rows / n_long / long_thresh: as for lkg_spmm_csr_f32 (one workgroup per long row).  */
+ * long_rows / n_long / long_thresh: as for lkg_spmm_csr_f32 (one workgroup per long row).
+ * n_rel: the rows of relemb (nn.Embedding(n_relations, relation_dim), model.py:276); every relation id in rel /
+ * rel_first is below it (the caller checks).  A table of at most 16 KB is staged in LDS per workgroup;
+ * 0 = unknown (the rows are fetched from global memory per entry).  */
 int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const int32_t *rowptr,
                          const int32_t *col, const int32_t *eptr, const int32_t *rel,
                          const int32_t *rel_first, const int32_t *dup_entries,
                          const int32_t *dup_rows, int32_t n_dup, int64_t entry_lo, int64_t entry_hi,
                          const float *ent, int64_t ld_ent, const float *relemb, int64_t ld_rel,
                          float *val_out, float *logits_out, const int32_t *long_rows, int32_t n_long,
-                         int32_t long_thresh, void *stream);
+                         int32_t long_thresh, int32_t n_rel, void *stream);
 
 /* dst[i] = src[perm[i]]  (attention values into CSC order after a refresh)     */
 int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src, float *dst, void *stream);

@@ -31,7 +31,7 @@ PROTOTYPES = {
     "lkg_csr_extract_rows": [i64, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_spmm_csr_scatter_bwd_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp],
     "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, vp, vp,
-                             i32, i32, vp],
+                             i32, i32, i32, vp],
     "lkg_permute_f32": [i64, vp, vp, vp, vp],
     "lkg_transe_score_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_loss_reduce_f32": [i64, vp, vp, f32, vp, vp],

@@ -13,6 +13,7 @@
 
 #include "lkg_common.h"
 
+
 namespace {
 
 template <typename V>
@@ -70,33 +71,53 @@ __global__ __launch_bounds__(256) void extra_relations_kernel(int n_dup, long ro
 //   blocks [0, n_long)   : one LONG head row (> long_thresh entries) per workgroup; the four waves take interleaved
 //                          64-entry chunks and meet in LDS for the softmax statistics;
 //   blocks [n_long, ...) : four ordinary rows, one wave each.
-template <typename V, int LPE, int CPL, int U, bool DUPS>
+template <typename V, int LPE, int CPL, int U, bool DUPS, bool RLDS>
 __global__ __launch_bounds__(256) void edge_softmax_kernel(
     int n_rows, long row_offset, int nchunk, const int *__restrict__ rowptr, const int *__restrict__ col,
     const int *__restrict__ eptr, const int *__restrict__ rel, const int *__restrict__ rel_first,
     const float *__restrict__ ent, long ld_ent, const float *__restrict__ relemb, long ld_rel,
     float *__restrict__ val_out, float *__restrict__ logits_out, const int *__restrict__ long_rows, int n_long,
-    int long_thresh) {
+    int long_thresh, int n_rel, int rows_per_wave) {
     using ops = dot_ops<V>;
     constexpr int EPW = 64 / LPE;
     __shared__ float red[4];
+    extern __shared__ __align__(16) unsigned char rel_lds_bytes[];
+    V *rel_lds = reinterpret_cast<V *>(rel_lds_bytes);
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const bool team = (int)blockIdx.x < n_long;      // workgroup-uniform
+    if constexpr (RLDS) {
+        // the relation table (n_rel x nchunk chunks) into LDS once per workgroup: every entry adds one of its rows to the
+        // head's, and fetched per entry from global memory those rows cost the texture path as much as the tails do
+        for (int i = threadIdx.x; i < n_rel * nchunk; i += 256) {
+            const int rr = i / nchunk;
+            rel_lds[i] = reinterpret_cast<const V *>(relemb + (long)rr * ld_rel)[i - rr * nchunk];
+        }
+        __syncthreads();
+    }
+    const int sub = lane / LPE;
+    const int sl = lane % LPE;
+    const int wave_i = team ? w : 0, n_waves = team ? 4 : 1;
+    // lanes whose chunk index falls outside the row contribute nothing
+    bool live[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) live[i] = (sl + i * LPE) < nchunk;
+
+    // team: ONE long row; otherwise rows_per_wave rows per wave, the four waves interleaved over 4 * rows_per_wave
+    // consecutive rows (1 without the LDS table: as many workgroups as row quadruples)
+    const int first = team ? 0 : ((int)blockIdx.x - n_long) * 4 * rows_per_wave + w;
+    for (int it = 0; it < (team ? 1 : rows_per_wave); ++it) {
     int row;
     if (team) {
         row = long_rows[blockIdx.x];
     } else {
-        row = ((int)blockIdx.x - n_long) * 4 + w;
-        if (row >= n_rows) return;
+        row = first + 4 * it;
+        if (row >= n_rows) break;
     }
     const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
     const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
-    if (start >= end) return;
-    if (!team && n_long > 0 && end - start > long_thresh) return;
-    const int sub = lane / LPE;
-    const int sl = lane % LPE;
-    const int wave_i = team ? w : 0, n_waves = team ? 4 : 1;
+    if (start >= end) continue;
+    if (!team && n_long > 0 && end - start > long_thresh) continue;
 
     // head embedding chunk(s) of this lane
     V hv[CPL];
@@ -105,11 +126,6 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 #pragma unroll
         for (int i = 0; i < CPL; ++i) hv[i] = hs[min(sl + i * LPE, nchunk - 1)];
     }
-    // lanes whose chunk index falls outside the row contribute nothing
-    bool live[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) live[i] = (sl + i * LPE) < nchunk;
-
     // rows of at most 64 entries (nearly all of them) never leave the registers: lane i keeps the logit of
     // entry i and the softmax statistics are two wave reductions; longer rows park their logits in val_out
     const bool in_regs = !team && end - start <= 64;
@@ -142,12 +158,16 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const V *ts = reinterpret_cast<const V *>(ent + (long)cc[u] * ld_ent);
-                const V *rs = reinterpret_cast<const V *>(relemb + (long)rr[u] * ld_rel);
+                const V *rs = RLDS ? rel_lds + rr[u] * nchunk : reinterpret_cast<const V *>(relemb + (long)rr[u] * ld_rel);
 #pragma unroll
                 for (int i = 0; i < CPL; ++i) {
                     const int chunk = min(sl + i * LPE, nchunk - 1);
                     tv[u][i] = ts[chunk];
-                    rv[u][i] = rs[chunk];
+                    if constexpr (!RLDS) rv[u][i] = rs[chunk];
+                }
+                if constexpr (RLDS) {        // (after the tails are requested: the LDS reads wait on lgkmcnt, not on them)
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) rv[u][i] = rs[min(sl + i * LPE, nchunk - 1)];
                 }
             }
 #pragma unroll
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
         const float e = has ? expf(mylogit - m) : 0.f;
         const float s = wave_sum(e);
         if (has) val_out[start + lane] = e / s;
-        return;
+        continue;
     }
     // the logits were written by other lanes (team: other waves) of this workgroup: make them visible
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -219,6 +239,7 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
         s = (red[0] + red[1]) + (red[2] + red[3]);
     }
     for (int j = start + tid; j < end; j += ts) val_out[j] = expf(val_out[j] - m) / s;
+    }   // rows of this wave
 }
 
 struct EsArgs {
@@ -234,9 +255,32 @@ struct EsArgs {
     float *val_out, *logits_out;
     const int *long_rows;
     int n_long, long_thresh;
+    int n_rel;
+    size_t chunk_bytes;
 };
 
-template <typename V, int LPE, int CPL, int U, bool DUPS>
+// The relation table is staged in LDS when it fits REL_LDS_BYTES: up to there the 160 KB of a CU hold the tables of as many
+// workgroups as the registers allow waves (8 per SIMD), and the refresh of the 10 M-edge graph at D = 256 with 16 relations
+// goes from 2.02 to 1.85 ms; a 32 KB table (5 workgroups per CU) already LOSES to the rows from global memory (2.37 vs
+// 2.10 ms), a 64 KB one takes 3.8 ms.  Each workgroup then works through ROWS_PER_WAVE_LDS rows per wave, so that the fill
+// is read once per ~600 entries.
+constexpr size_t REL_LDS_BYTES = 16 * 1024;
+constexpr int ROWS_PER_WAVE_LDS = 16;
+
+template <typename V, int LPE, int CPL, int U, bool DUPS, bool RLDS>
+int launch3(const EsArgs &a, hipStream_t s) {
+    const int rpw = RLDS ? ROWS_PER_WAVE_LDS : 1;
+    const size_t lds = RLDS ? (size_t)a.n_rel * a.nchunk * a.chunk_bytes : 0;
+    const int64_t blocks = (a.n_rows + 4 * rpw - 1) / (4 * rpw) + a.n_long;
+    hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, DUPS, RLDS>), dim3((unsigned)blocks), dim3(256), lds, s,
+                       (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col, a.eptr, a.rel, a.rel_first, a.ent,
+                       (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out, a.logits_out, a.long_rows, a.n_long,
+                       a.long_thresh, a.n_rel, rpw);
+    LKG_CHECK_LAUNCH("lkg_edge_softmax_f32");
+    return LKG_OK;
+}
+
+template <typename V, int LPE, int CPL, int U, int U_LDS, bool DUPS>
 int launch2(const EsArgs &a, hipStream_t s) {
     if constexpr (DUPS) {
         // only THIS call's entries: a row-range refresh into an existing value array leaves the other rows alone
@@ -249,32 +293,29 @@ int launch2(const EsArgs &a, hipStream_t s) {
                                a.n_dup, (long)a.row_offset, a.nchunk, a.dup_entries, a.dup_rows, a.col, a.eptr, a.rel,
                                a.ent, (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out);
     }
-    const int64_t blocks = (a.n_rows + 3) / 4 + a.n_long;
-    hipLaunchKernelGGL((edge_softmax_kernel<V, LPE, CPL, U, DUPS>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (int)a.n_rows, (long)a.row_offset, a.nchunk, a.rowptr, a.col, a.eptr, a.rel, a.rel_first, a.ent,
-                       (long)a.ld_ent, a.relemb, (long)a.ld_rel, a.val_out, a.logits_out, a.long_rows, a.n_long,
-                       a.long_thresh);
-    LKG_CHECK_LAUNCH("lkg_edge_softmax_f32");
-    return LKG_OK;
+    if (a.n_rel > 0 && (size_t)a.n_rel * a.nchunk * a.chunk_bytes <= REL_LDS_BYTES)
+        return launch3<V, LPE, CPL, U_LDS, DUPS, true>(a, s);
+    return launch3<V, LPE, CPL, U, DUPS, false>(a, s);
 }
 
-template <typename V, int LPE, int CPL, int U>
+template <typename V, int LPE, int CPL, int U, int U_LDS>
 int launch(const EsArgs &a, hipStream_t s) {
-    return a.eptr ? launch2<V, LPE, CPL, U, true>(a, s) : launch2<V, LPE, CPL, U, false>(a, s);
+    return a.eptr ? launch2<V, LPE, CPL, U, U_LDS, true>(a, s) : launch2<V, LPE, CPL, U, U_LDS, false>(a, s);
 }
 
 template <typename V>
 int dispatch(const EsArgs &a, hipStream_t s) {
     const int nchunk = a.nchunk;
     // U = 2 entries in flight per sub-group: measured best on one box (D=256 zipf: U=1 2.65 ms, U=2 2.29, U=4 2.63 --
-    // at U=4 the 91 VGPRs of the tanh temporaries cut the occupancy to 5 waves per SIMD)
-    if (nchunk <= 8) return launch<V, 8, 1, 2>(a, s);
-    if (nchunk <= 16) return launch<V, 16, 1, 2>(a, s);
-    if (nchunk <= 32) return launch<V, 32, 1, 2>(a, s);
-    if (nchunk <= 64) return launch<V, 64, 1, 2>(a, s);   // (after the VALU reductions: U=3 the same, U=4 slower)
-    if (nchunk <= 128) return launch<V, 64, 2, 2>(a, s);
-    if (nchunk <= 192) return launch<V, 64, 3, 2>(a, s);
-    if (nchunk <= 256) return launch<V, 64, 4, 1>(a, s);
+    // at U=4 the 91 VGPRs of the tanh temporaries cut the occupancy to 5 waves per SIMD).  U_LDS: the same with the
+    // relation rows out of LDS (D=256, 16 relations: 2, 3 and 4 within 1 % of each other at 1.85 ms, 6 slower)
+    if (nchunk <= 8) return launch<V, 8, 1, 2, 2>(a, s);
+    if (nchunk <= 16) return launch<V, 16, 1, 2, 2>(a, s);
+    if (nchunk <= 32) return launch<V, 32, 1, 2, 2>(a, s);
+    if (nchunk <= 64) return launch<V, 64, 1, 2, 2>(a, s);   // (after the VALU reductions: U=3 the same, U=4 slower)
+    if (nchunk <= 128) return launch<V, 64, 2, 2, 2>(a, s);
+    if (nchunk <= 192) return launch<V, 64, 3, 2, 2>(a, s);
+    if (nchunk <= 256) return launch<V, 64, 4, 1, 1>(a, s);
     lkg_set_error("lkg_edge_softmax_f32: embedding width of %d chunks exceeds the supported 256", nchunk);
     return LKG_ERR_UNSUPPORTED;
 }
@@ -287,8 +328,10 @@ extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t 
                                     int32_t n_dup, int64_t entry_lo, int64_t entry_hi, const float *ent,
                                     int64_t ld_ent,
                                     const float *relemb, int64_t ld_rel, float *val_out, float *logits_out,
-                                    const int32_t *long_rows, int32_t n_long, int32_t long_thresh, void *stream) {
+                                    const int32_t *long_rows, int32_t n_long, int32_t long_thresh, int32_t n_rel,
+                                    void *stream) {
     LKG_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && row_offset >= 0, "lkg_edge_softmax_f32: bad row range");
+    LKG_REQUIRE(n_rel >= 0, "lkg_edge_softmax_f32: negative relation count");
     LKG_REQUIRE(d > 0 && ld_ent >= d && ld_rel >= d, "lkg_edge_softmax_f32: bad d/strides (d=%d)", d);
     LKG_REQUIRE(n_long >= 0 && (n_long == 0 || (long_rows && long_thresh >= 64)),
                 "lkg_edge_softmax_f32: long-row list needs a pointer and a threshold >= 64");
@@ -300,7 +343,7 @@ extern "C" int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t 
     const bool vec = (d % 4 == 0) && (ld_ent % 4 == 0) && (ld_rel % 4 == 0) && lkg_aligned16(ent) && lkg_aligned16(relemb);
     EsArgs a{n_rows, row_offset, vec ? d / 4 : d, rowptr, col, eptr, rel, rel_first, dup_entries, dup_rows, n_dup,
              entry_lo, entry_hi, ent, ld_ent, relemb, ld_rel,
-             val_out, logits_out, long_rows, n_long, long_thresh};
+             val_out, logits_out, long_rows, n_long, long_thresh, n_rel, vec ? sizeof(float4) : sizeof(float)};
     hipStream_t s = (hipStream_t)stream;
     return vec ? dispatch<float4>(a, s) : dispatch<float>(a, s);
 }

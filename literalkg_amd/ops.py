@@ -650,7 +650,7 @@ def edge_softmax(g: KGStructure, ent: torch.Tensor, relemb: torch.Tensor, want_l
            N.ptr(g.col), N.ptr(g.eptr), N.ptr(g.rel), N.ptr(g.rel_first), *dup, e_lo, e_hi,
            N.ptr(ent), _ld(ent), N.ptr(relemb), _ld(relemb), N.ptr(val),
            N.ptr(logits), N.ptr(long_rows), 0 if long_rows is None else long_rows.numel(), LONG_ROW_THRESHOLD,
-           _stream())
+           relemb.shape[0], _stream())
     return val, logits
 
 

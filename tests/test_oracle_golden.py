@@ -195,3 +195,40 @@ def test_sampler_oracle_reproduces_the_reference_batches():
         for hh, rr, pp, negs in zip(bh[::k], br[::k], bp[::k], bn.reshape(-1, k)):
             assert (hh, rr, pp) in pos and len(set(negs.tolist())) == k
             assert all((hh, rr, x) not in pos for x in negs)
+
+
+# ----------------------------------------------------------------------------- the fuzz sweep's second arbiter
+@pytest.mark.parametrize("agg", ["gcn", "graphsage", "bi-interaction", "gin"])
+def test_device_association_of_the_residual_products_is_the_same_function(agg):
+    """tests/test_gpu_fuzz.py arbitrates gradient differences next to a LeakyReLU kink with the oracle evaluated in the DEVICE's
+    association of the residual layers' products (two small matrices first, one N-row product).  In float64 that restatement
+    must be the oracle itself: loss and every gradient to 1e-11 on a three-layer residual model of each aggregator."""
+    from test_gpu_fuzz import device_association
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    import literalkg_amd as L
+    n, dim = 400, 24
+    h, t, r = make_kg(n, 1600, "uniform", seed=3)
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=3, aggregation_type=agg,
+                        use_residual=True, scale_gat_dim=20, mlp_hidden_dim=16)
+    torch.manual_seed(2)
+    a_in = io.initial_a_in(n, h, t, r).double()
+    m = L.LiteralKG(cfg, n, 16, io.initial_a_in(n, h, t, r), None, None)
+    params = {k: v.detach().double() for k, v in m.state_dict().items() if k != "A_in"}
+    batch = [torch.from_numpy(x) for x in make_batch(n, 30, 3, seed=4)]
+
+    def grads(device_form):
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        if device_form:
+            with device_association(O):
+                loss = O.pre_training_loss(p, cfg, a_in, *batch)
+        else:
+            loss = O.pre_training_loss(p, cfg, a_in, *batch)
+        loss.backward()
+        return float(loss), {k: v.grad for k, v in p.items() if v.grad is not None}
+
+    (l0, g0), (l1, g1) = grads(False), grads(True)
+    assert abs(l0 - l1) <= 1e-12 * abs(l0)
+    assert g0.keys() == g1.keys() and any("linear_h0" in k for k in g0)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-11 * (float(g0[k].abs().max()) + 1e-300), k
