@@ -686,8 +686,9 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
         return LKG_ERR_HIP;
     }
     const bool listed = rows_with_entries != nullptr;
-    LKG_REQUIRE(!listed || (rows_without_entries && !x_rows && !out_rows && n_rows_with_entries >= 0 &&
-                            n_rows_without_entries >= 0 && n_rows_with_entries + n_rows_without_entries == n_rows),
+    LKG_REQUIRE(!listed || ((rows_without_entries || n_rows_without_entries == 0) && !x_rows && !out_rows &&
+                            n_rows_with_entries >= 0 && n_rows_without_entries >= 0 &&
+                            n_rows_with_entries + n_rows_without_entries == n_rows),
                 "lkg_spmm_csr_fused_f32: the row lists must partition the %lld rows (and exclude x_rows / out_rows)",
                 (long long)n_rows);
     const SpmmExtra ex{add2, (long)ld_add2, add2 ? add2_rows : nullptr, copy_dst ? copy_src : nullptr, (long)ld_copy_src, copy_dst,

@@ -296,7 +296,7 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
 
 
 # ============================================================================= the fused SpMM entry point, option by option
-SPMM_CASES = int(os.environ.get("LKG_FUZZ_SPMM_CASES", "60"))
+SPMM_CASES = int(os.environ.get("LKG_FUZZ_SPMM_CASES", "150"))
 
 
 def draw_csr(rng, n_rows, n_cols, mean_deg, share_empty, n_long, gpu_device):
@@ -340,7 +340,9 @@ def test_fused_spmm_options_against_a_float64_product(gpu_device, seed):
         opt["copy"] = opt["rowmax"] = False                # (the rows-written form excludes both, lkg_spmm.hip)
     if opt["add_self"] and n_x != n_rows:
         opt["add_self"] = False
-    kw, nan = {}, float("nan")
+    # (operands declared zero outside their flags hold NaN there where the kernel promises not to read them: on the 16-byte
+    # path; the scalar path ignores the flags -- include/literalkg_hip.h -- and reads the zeros)
+    kw, nan = {}, float("nan") if vec else 0.0
     x64 = x.double()
     if opt["x_rows"]:
         flags = (torch.rand(n_x, device=gpu_device) < pick([0.05, 0.5])).to(torch.uint8)
@@ -409,3 +411,70 @@ def test_fused_spmm_options_against_a_float64_product(gpu_device, seed):
         assert torch.equal(cdst, kw["copy"][0]), what
     if rm is not None:
         torch.testing.assert_close(rm.double(), want.abs().amax(1), rtol=1e-5, atol=2e-5 * scale)
+
+
+# ============================================================================= the attention refresh, shape by shape
+ATT_CASES = int(os.environ.get("LKG_FUZZ_ATT_CASES", "80"))
+
+
+@pytest.mark.parametrize("seed", [9000 + i for i in range(ATT_CASES)])
+def test_attention_refresh_against_the_oracle_over_drawn_shapes(L, O, gpu_device, seed):
+    """lkg_edge_softmax_f32 over drawn graphs (empty rows, rows of 1 / <= 64 / > 64 / > 256 entries, (h, t) pairs under two and
+    three relations or none at all), widths on the 16-byte and the scalar path, relation tables that fit the LDS stage and
+    tables that do not, embeddings inside and outside the tanh series' range, whole-graph and row-range refreshes: coalesced
+    indices bit for bit, values to 1e-4 against the oracle's explicit form (logit, merge, row softmax)."""
+    from literalkg_amd import ops
+    rng = np.random.default_rng(seed)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    n = int(pick([40, 500, 3000]))
+    d = int(pick([4, 8, 30, 64, 100, 128, 256, 300, 512, 1024]))
+    n_rel = int(pick([1, 2, 6, 16, 40, 130]))
+    e = int(n * pick([1, 4, 15]))
+    h = (n * rng.random(e) ** pick([1.0, 1.7, 3.0])).astype(np.int64)
+    t, r = rng.integers(0, n, e), rng.integers(0, n_rel, e)
+    for row, deg in [(int(rng.integers(n)), int(pick([65, 70, 200, 257, 333, 900]))) for _ in range(int(pick([0, 1, 3])))]:
+        h = np.concatenate([h, np.full(deg, row)])
+        t = np.concatenate([t, rng.choice(n, deg, replace=deg > n)])
+        r = np.concatenate([r, rng.integers(0, n_rel, deg)])
+    trip = np.stack([h, r, t], 1)
+    if n_rel > 1 and rng.random() < 0.7:        # the same (h, t) under a second and a third relation
+        k2, k3 = int(len(trip) * pick([0.01, 0.2])), int(len(trip) * 0.02)
+        trip = np.concatenate([trip, np.stack([h[:k2], (r[:k2] + 1) % n_rel, t[:k2]], 1),
+                               np.stack([h[:k3], (r[:k3] + 2) % n_rel, t[:k3]], 1)])
+    trip = np.unique(trip, axis=0)
+    trip = trip[(trip[:, 0] % 11) != 3]          # some head rows stay empty
+    trip = trip[rng.permutation(len(trip))]
+    if len(trip) == 0:
+        trip = np.array([[0, 0, 0]])
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    # |h + r| below 0.25 everywhere: the tanh series alone; larger: the exp / rcp form -- in a few columns only at the larger
+    # widths, so that the logits stay O(1) (the oracle forms them in fp32 like the reference: at |logit| ~ 50 its own rounding
+    # would exceed the 1e-4 the values are held to)
+    mag = pick([0.02, 0.3, 1.5])
+    ent, rel = torch.randn(n, d) * mag, torch.randn(n_rel, d) * mag
+    if mag * mag * d > 8:
+        keep = torch.zeros(d)
+        keep[rng.choice(d, max(1, int(8 / (mag * mag))), replace=False)] = 1.0
+        ent, rel = ent * (keep + (1 - keep) * 0.02 / mag), rel * (keep + (1 - keep) * 0.02 / mag)
+    g = L.KGStructure.from_triples(n, h, t, r, device=gpu_device)
+    what = (seed, n, d, n_rel, len(trip), mag, g.has_dups)
+    val, logits = ops.edge_softmax(g, ent.to(gpu_device), rel.to(gpu_device), want_logits=bool(rng.random() < 0.3))
+    rows, cols, want = O.attention_refresh_explicit(n, ent, rel, *(torch.from_numpy(a) for a in (h, t, r)))
+    assert torch.equal(g.coo_indices().cpu(), torch.stack([rows, cols])), what
+    torch.testing.assert_close(val.cpu(), want, rtol=1e-4, atol=1e-6, msg=lambda m: f"{what}: {m}")
+    if logits is not None:                       # the merged pre-softmax logits: the row softmax of them is the value array
+        lg = logits.cpu().double()
+        rp = g.host("rowptr")
+        for row in rng.choice(n, min(n, 20), replace=False):
+            a, b = int(rp[row]), int(rp[row + 1])
+            if b > a:
+                torch.testing.assert_close(torch.softmax(lg[a:b], 0).float(), want[a:b], rtol=1e-4, atol=1e-6)
+    # a row range into an existing array: the other rows' entries keep what they held
+    lo = int(rng.integers(0, n))
+    hi = int(rng.integers(lo, n + 1))
+    out = torch.full((g.nnz,), -7.0, device=gpu_device)
+    ops.edge_softmax(g, ent.to(gpu_device), rel.to(gpu_device), row_lo=lo, row_hi=hi, out=out)
+    rp = g.host("rowptr")
+    a, b = int(rp[lo]), int(rp[hi])
+    torch.testing.assert_close(out[a:b].cpu(), want[a:b], rtol=1e-4, atol=1e-6, msg=lambda m: f"{what} rows [{lo}, {hi}): {m}")
+    assert bool((out[:a] == -7.0).all()) and bool((out[b:] == -7.0).all()), what
