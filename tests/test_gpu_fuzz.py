@@ -478,3 +478,86 @@ def test_attention_refresh_against_the_oracle_over_drawn_shapes(L, O, gpu_device
     a, b = int(rp[lo]), int(rp[hi])
     torch.testing.assert_close(out[a:b].cpu(), want[a:b], rtol=1e-4, atol=1e-6, msg=lambda m: f"{what} rows [{lo}, {hi}): {m}")
     assert bool((out[:a] == -7.0).all()) and bool((out[b:] == -7.0).all()), what
+
+
+# ============================================================================= the structure build: device against host
+BUILD_CASES = int(os.environ.get("LKG_FUZZ_BUILD_CASES", "60"))
+
+
+@pytest.mark.parametrize("seed", [11000 + i for i in range(BUILD_CASES)])
+def test_device_structure_build_equals_the_host_build_on_drawn_edge_lists(L, gpu_device, seed):
+    """lkg_csr_build_device / lkg_csr_transpose_device (radix sort + scans on the GPU) against lkg_csr_build / lkg_csr_transpose
+    (host) on drawn edge lists -- sizes around the sort's digit and block boundaries, id spaces from 1 to 2^21, heavy heads,
+    repeated (h, t) pairs under other relations and exact duplicate triples, no edges at all: every array bit for bit."""
+    rng = np.random.default_rng(seed)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    n = int(pick([1, 2, 255, 256, 257, 4096, 65_535, 65_537, 300_000, 2_097_152]))
+    e = int(pick([0, 1, 2, 255, 256, 257, 1023, 1025, 4097, 70_000, 250_001]))
+    n_rel = int(pick([1, 2, 16, 255, 1000]))
+    h = (n * rng.random(e) ** pick([1.0, 2.0, 6.0])).astype(np.int64)
+    t, r = rng.integers(0, n, e), rng.integers(0, n_rel, e)
+    if e > 4 and rng.random() < 0.6:
+        k = int(rng.integers(1, e // 2 + 1))
+        src = rng.integers(0, e, k)
+        h, t = np.concatenate([h, h[src]]), np.concatenate([t, t[src]])
+        r = np.concatenate([r, np.where(rng.random(k) < 0.5, r[src], (r[src] + 1) % n_rel)])     # exact repeats and other relations
+    gh = L.KGStructure.from_triples(n, h, t, r, device="cpu")
+    inputs = (h, t, r) if rng.random() < 0.5 else tuple(torch.from_numpy(x).to(gpu_device) for x in (h, t, r))
+    gd = L.KGStructure.from_triples(n, *inputs, device=gpu_device)
+    what = (seed, n, len(h), n_rel)
+    assert (gd.n, gd.nnz, gd.n_raw) == (gh.n, gh.nnz, gh.n_raw), what
+    for name in ("rowptr", "col", "eptr", "rel", "rel_first", "dup_entries", "dup_rows", "t_rowptr", "t_col", "t_perm"):
+        a, b = gd.host(name), gh.host(name)
+        assert (a is None) == (b is None), (name, what)
+        if a is not None:
+            assert a.dtype == b.dtype and np.array_equal(a, b), (name, what)
+    assert np.array_equal(gd.order, gh.order), what
+
+
+# ============================================================================= the tall GEMM, shape by shape
+TALL_CASES = int(os.environ.get("LKG_FUZZ_TALL_CASES", "30"))
+
+
+@pytest.mark.parametrize("seed", [13000 + i for i in range(TALL_CASES)])
+def test_tall_gemm_against_float64_over_drawn_shapes(gpu_device, seed):
+    """lkg_gemm_tall_f32 (one to three K-panels from different arrays, aligned and unaligned, strided; output widths across the
+    column-tile boundary; both weight layouts; alpha / beta / bias; row counts off the 128-row tile) against the float64
+    product: within 3 x an fp32 GEMM's own error of the same product (2e-6 of the largest entry at least)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from literalkg_amd import ops
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    m = int(pick([16384, 16385, 16384 + 127, 20_000, 33_333]))
+    n = int(pick([1, 5, 32, 50, 64, 100, 128, 200, 255, 256, 257, 300, 384, 512]))
+    ks = [int(pick([1, 2, 3, 7, 16, 30, 64, 100, 128, 255, 256, 300])) for _ in range(int(pick([1, 2, 3])))]
+    tb = bool(rng.random() < 0.7)
+    if not ops.tall_ok(m, n, ks, single_panel_too=True):
+        pytest.skip(f"not a product the tall engine takes: {m} x {n} x {ks}")
+
+    def panel(k):
+        kind = pick(["plain", "offset", "wide"])
+        if kind == "plain":
+            return torch.randn(m, k, generator=gen).to(gpu_device)
+        off = int(pick([1, 3, 4]))
+        return torch.randn(m, k + off + 2, generator=gen).to(gpu_device)[:, off:off + k]
+    panels = [panel(k) for k in ks]
+    blocks = [(torch.randn((n, k) if tb else (k, n), generator=gen) * 0.1).to(gpu_device) for k in ks]
+    a64 = torch.cat([p.double() for p in panels], 1)
+    b64 = torch.cat([b.double() if tb else b.double().t() for b in blocks], 1)
+    want = a64 @ b64.t()
+    scale = float(want.abs().max()) + 1e-30
+    f32 = float(((a64.float() @ b64.float().t()).double() - want).abs().max()) / scale
+    what = (seed, m, n, ks, tb)
+    got = ops.gemm_tall(panels, (blocks,), tb)
+    err = float((got.double() - want).abs().max()) / scale
+    # (floor: the operands carry 22 significant bits -- a K = 1 "product" is 2^-22 off where an fp32 multiply is 2^-24 off)
+    assert err <= max(3.0 * f32, 2e-6), (what, err, f32)
+    bias = torch.randn(n, generator=gen).to(gpu_device)
+    alpha, beta = float(pick([1.0, 0.5, -2.0])), float(pick([0.0, 1.0, 2.0]))
+    c0 = torch.randn(m, n + 5, generator=gen).to(gpu_device)[:, 5:] if rng.random() < 0.5 else torch.randn(m, n, generator=gen).to(gpu_device)
+    got2 = ops.gemm_tall(panels, (blocks,), tb, bias, alpha=alpha, beta=beta, out=c0.clone())
+    want2 = alpha * want + beta * c0.double() + bias.double()
+    scale2 = float(want2.abs().max()) + 1e-30
+    assert float((got2.double() - want2).abs().max()) / scale2 <= max(6.0 * f32, 4e-6), (what, alpha, beta)
