@@ -143,3 +143,126 @@ def test_frontier_exchange_equals_the_dense_exchange_on_the_kernels(gpu_device, 
         p.join(60)
     bad = [(r, msg) for r, msg in res if msg != "ok"]
     assert not bad, bad
+
+
+# ----------------------------------------------------------------------------- drawn configurations: sharded == single
+def _sweep_worker(rank, world, port, seeds, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import literalkg_amd as L
+        from literalkg_amd import distributed as D, io
+        from literalkg_amd.synth import make_batch, make_kg
+        from oracle import literalkg_oracle as O
+        from test_gpu_fuzz import draw
+        done = []
+        for seed in seeds:
+            c = draw(seed)
+            rng = np.random.default_rng(seed + 17)
+            scheme = ["rows", "features"][int(rng.integers(2))]
+            sparse = ["auto", "always", "never"][int(rng.integers(3))]
+            partition = [None, "rows", "entries"][int(rng.integers(3))]
+            n, n_rel = min(c["n"], 20_000), c["n_rel"]
+            h, t, r = make_kg(n, min(c["e"], 8 * n), c["skew"], seed=seed)
+            r = np.random.default_rng(seed + 1).integers(0, n_rel, len(r))
+            _, first = np.unique(np.stack([h, r, t], 1), axis=0, return_index=True)
+            h, t, r = h[first], t[first], r[first]
+            cfg = O.default_cfg(embed_dim=c["dim"], relation_dim=c["rel_dim"], conv_dim=c["conv"], n_conv_layers=c["layers"],
+                                aggregation_type=c["agg"], scale_gat_dim=c["scale"], use_residual=c["residual"],
+                                use_num_lit=c["gate"] in ("mul", "num"), use_txt_lit=c["gate"] in ("mul", "txt"),
+                                txt_lit_dim=c["txt_dim"], mlp_hidden_dim=c["mlp_hidden"], kg_l2loss_lambda=1e-4,
+                                fine_tuning_l2loss_lambda=1e-4, pre_training_neg_rate=c["neg"], fine_tuning_neg_rate=c["neg"],
+                                device=dev)
+            for attempt in range(3):             # (a LeakyReLU input within rounding of zero: other values, see test_gpu_fuzz.py)
+                vs = seed + 7919 * attempt
+                torch.manual_seed(vs)
+                num = torch.rand(n, 2) if cfg.use_num_lit else None
+                txt = torch.randn(n, cfg.txt_lit_dim) if cfg.use_txt_lit else None
+                a_in = io.initial_a_in(n, h, t, r)
+                full = L.LiteralKG(cfg, n, n_rel, a_in, num, txt, scoring=c["scoring"])
+                with torch.no_grad():
+                    full.entity_embed.weight.mul_(c["weight_scale"])
+                state = {k: v.detach().clone() for k, v in full.state_dict().items()}
+                bh, br, bp, bn = (torch.from_numpy(x).to(dev) for x in make_batch(n, c["batch"], c["neg"], seed=vs + 2))
+                br = torch.from_numpy(np.repeat(np.random.default_rng(vs + 3).integers(0, n_rel, c["batch"]), c["neg"])).to(dev)
+                full.to(dev).eval()
+                m = D.ShardedLiteralKG.from_full(cfg, n, n_rel, state, num, txt, scoring=c["scoring"], scheme=scheme, device=dev,
+                                                 sparse_backward=sparse, partition=partition).eval()
+                worst = 0.0
+                what = (seed, scheme, sparse, partition, c)
+                for mode, args in (("pre_training", (bh, br, bp, bn)), ("fine_tuning", (bh, bp, bn))):
+                    full.zero_grad(set_to_none=True)
+                    m.zero_grad(set_to_none=True)
+                    want = full(*args, device=dev, mode=mode)
+                    want.backward()
+                    got = m(*args, device=dev, mode=mode)
+                    got.backward()
+                    m.sync_gradients()
+                    assert abs(float(got.detach()) - float(want.detach())) <= 2e-5 * max(1.0, abs(float(want.detach()))), (mode, what, float(got.detach()), float(want.detach()))
+                    ref = dict(full.named_parameters())
+                    for k, p in m.local.named_parameters():
+                        if p.grad is None or k == "A_in":
+                            continue
+                        w = ref[k].grad
+                        if w is None:            # (a parameter this configuration never uses: sync_gradients' fixed bucket
+                            assert float(p.grad.abs().max()) == 0.0, (k, what)      # holds zeros for it)
+                            continue
+                        if k == "entity_embed.weight":
+                            w = w[m.part.lo:m.part.hi]
+                        scale = float(ref[k].grad.abs().max()) + 1e-30
+                        worst = max(worst, float((p.grad - w).abs().max()) / scale if w.numel() else 0.0)
+                # every rank takes the same decision
+                flag = torch.tensor([worst])
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if float(flag) < 2e-3:
+                    break
+                assert attempt < 2, ("gradients differ on every draw of the values", float(flag), what)
+            # the inference heads: scores of the sharded module == the single module's
+            hid, tid = bh[:40], bp[:50]
+            with torch.no_grad():
+                got_s, want_s = m.local.calc_score(hid, tid), full.calc_score(hid, tid)
+                assert float((got_s - want_s).abs().max()) <= 1e-4 * (float(want_s.abs().max()) + 1e-30), what
+            done.append(seed)
+            if rank == 0:
+                print(f"sharded sweep: seed {seed} {scheme} / {sparse} / {partition} n={n} {c['agg']} x{c['layers']} "
+                      f"dim {c['dim']} gate {c['gate']} {c['scoring']}: worst gradient distance {worst:.2e}", flush=True)
+            del m, full
+        assert done == list(seeds), (done, seeds)
+        q.put((rank, "ok"))
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-4000:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,first_seed", [(2, 21000), (3, 22000)])
+def test_sharded_module_equals_the_single_module_on_drawn_configurations(gpu_device, world, first_seed):
+    """Configurations drawn like tests/test_gpu_fuzz.py's (aggregator, layers, widths, residual, gate, scale_gat_dim, scoring,
+    graph, batch), with a drawn scheme ("rows" / "features"), backward exchange ("auto" / "always" / "never") and row
+    partition: the row-sharded module on `world` ranks (one GPU, gloo transport, the real kernels) against the single module
+    on the same device -- pre-training and fine-tuning loss, every gradient (the entity table by this rank's rows, the
+    replicated weights after sync_gradients), link scores.  LKG_FUZZ_SHARDED_CASES cases per world (default 20)."""
+    import __graft_entry__ as ge
+    ge.build()
+    k = int(os.environ.get("LKG_FUZZ_SHARDED_CASES", "20"))
+    seeds = [int(x) for x in os.environ.get("LKG_FUZZ_SHARDED_SEEDS", "").split(",") if x] or [first_seed + i for i in range(k)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, seeds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=840) for _ in procs]
+    for p in procs:
+        p.join(60)
+    bad = [(r, msg) for r, msg in res if msg != "ok"]
+    for r, msg in bad:
+        print(f"---- rank {r}\n{msg}")
+    assert not bad, f"{len(bad)} of {world} ranks failed (their tracebacks are in the captured output)"
