@@ -332,7 +332,8 @@ def test_fused_gate_matches_oracle_and_the_unfused_path(L, ops, O, gpu_device):
     gate (forward, input gradient, every weight gradient), with literal widths that are not multiples of 4."""
     torch.manual_seed(2)
     n = 16384 + 333
-    for d, nn_, nt in ((64, 2, 300), (48, 3, 7), (256, 2, 20)):
+    # (300 / 320 / 288 wide: the last column tile of the stacked product is mostly padding)
+    for d, nn_, nt in ((64, 2, 300), (48, 3, 7), (256, 2, 20), (300, 2, 300), (320, 3, 16), (288, 2, 5)):
         gate = L.GateMul(d, nn_, nt).to(gpu_device)
         x = (torch.randn(n, d) * 0.5).to(gpu_device).requires_grad_(True)
         num, txt = torch.rand(n, nn_).to(gpu_device), torch.randn(n, nt).to(gpu_device)
