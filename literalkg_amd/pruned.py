@@ -112,8 +112,9 @@ class _CompactAggregate(Function):
         sub = ctx.sub
         g = ops._f32_rows(g)
         gs = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
-        N.call("lkg_spmm_csr_scatter_bwd_f32", sub.n_rows, g.shape[1], N.ptr(sub.rowptr), N.ptr(sub.col),
-               N.ptr(sub.val), N.ptr(g), ops._ld(g), N.ptr(gs), ops._ld(gs), ops._stream())
+        if sub.col.numel():                      # (a batch whose rows have no stored entry: nothing reaches the source rows)
+            N.call("lkg_spmm_csr_scatter_bwd_f32", sub.n_rows, g.shape[1], N.ptr(sub.rowptr), N.ptr(sub.col),
+                   N.ptr(sub.val), N.ptr(g), ops._ld(g), N.ptr(gs), ops._ld(gs), ops._stream())
         return gs, (g if ctx.has_own else None), None
 
 

@@ -2,7 +2,7 @@
 The hand-picked parity cases of test_gpu_parity.py pin the families; this sweep draws COMBINATIONS nobody picked (odd widths
 behind gates, one relation, batches of one, row-sparse machinery on or off, pruning on or off) and checks, per case,
    the pre-training loss, the propagated table and every parameter gradient,
-   the fine-tuning loss and its gradients,
+   the fine-tuning loss and its gradients, the MLP head in training mode (output and gradients),
    the link scores (calc_score) and the attention refresh,
 each against oracle/literalkg_oracle.py on the same seeded inputs (1e-4 of the largest entry on values, 2e-3 on gradients --
 the tolerances of the hand-picked cases; where a drawn configuration is ill-conditioned in fp32 the oracle is also evaluated
@@ -76,7 +76,7 @@ class NearKink(AssertionError):
 REPORT = bool(os.environ.get("LKG_FUZZ_REPORT"))      # print every comparison's three distances instead of stopping at the first
 
 
-def within_reference_noise(got, want32, want64, tol, what, kink=None, alt32=None):
+def within_reference_noise(got, want32, want64, tol, what, kink=None, alt32=None, floor=0.0):
     """`got` (HIP, fp32) against the fp32 oracle within `tol` of the largest entry.  Two properties of the reference's OWN fp32
     path keep a drawn configuration from meeting that, and both are decided against the oracle evaluated in float64:
       * ill-conditioning (the residual mix multiplies by a matrix of near-equal entries and LayerNorm then removes the common
@@ -90,8 +90,8 @@ def within_reference_noise(got, want32, want64, tol, what, kink=None, alt32=None
         other side of a kink, not a kernel's doing (seed 3130: four parameters off by 0.3 - 1.5 %, each reproduced to three
         digits) -- and, failing that, NearKink: the test draws the SAME configuration with other values, twice at most; a
         wrong kernel fails every time, a coin does not."""
-    scale = float(want32.abs().max()) + 1e-12
-    err = float((got - want32).abs().max()) / scale
+    scale = max(float(want32.abs().max()), floor) + 1e-12    # (floor: a gradient that is zero next to the model's others --
+    err = float((got - want32).abs().max()) / scale          # a saturated sigmoid in front of fc3 -- is compared on their scale)
     if REPORT:
         t = want64()
         mine, noise = float((got.double() - t).abs().max()) / scale, float((want32.double() - t).abs().max()) / scale
@@ -121,13 +121,16 @@ def within_reference_noise(got, want32, want64, tol, what, kink=None, alt32=None
 
 
 def close_grads(named, ref, ref64, tag, ref32_device=None):
+    named = list(named)
+    largest = max([float(ref[k].grad.abs().max()) for k, v in named if v.grad is not None and k != "A_in"
+                   and ref[k].grad is not None] + [0.0])
     for k, v in named:
         if v.grad is None or k == "A_in":
             continue
         assert ref[k].grad is not None, (tag, k)
         within_reference_noise(v.grad.cpu(), ref[k].grad, lambda: ref64()[k].grad, 2e-3, (tag, k),
                                kink=lambda: ref64()["smallest relative LeakyReLU input"],
-                               alt32=None if ref32_device is None else (lambda: ref32_device()[k].grad))
+                               alt32=None if ref32_device is None else (lambda: ref32_device()[k].grad), floor=1e-6 * largest)
 
 
 class device_association:
@@ -210,15 +213,15 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
     br = torch.from_numpy(np.repeat(np.random.default_rng(value_seed + 3).integers(0, n_rel, c["batch"]), c["neg"]))
     dev = lambda *xs: [x.to(gpu_device) for x in xs]
 
-    def in_f64(loss_of):
+    def in_f64(loss_of, params=params):
         """the oracle in float64 on the same inputs (evaluated once, only when a comparison asks for it)"""
         memo = {}
 
         def run():
             if not memo:
                 dd = lambda x: None if x is None else x.double()
-                p64 = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point())
-                       for k, v in params.items()}
+                p64 = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(
+                    v.is_floating_point() and "running_" not in k) for k, v in params.items()}
                 seen, act = [], O._act
 
                 def spy(x):
@@ -234,13 +237,13 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
             return memo
         return run
 
-    def in_f32_device(loss_of):
+    def in_f32_device(loss_of, params=params):
         """the fp32 oracle in the device's association of the residual products (None without residual layers)"""
         memo = {}
 
         def run():
             if not memo:
-                q = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+                q = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in params.items()}
                 with device_association(O):
                     loss_of(q, a_in, num, txt).backward()
                 memo.update(q)
@@ -280,6 +283,37 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
         got = m.calc_score(*dev(heads, tails))
     within_reference_noise(got.cpu(), O.link_scores(gat, heads, tails), lambda: O.link_scores(gat64(), heads, tails), 1e-4,
                            f"link scores, case {seed}")
+
+    # ---- the MLP head (mode 'mlp', model.py:493-519 / model_bce.py:423-436) in training mode: batch statistics, every gradient
+    if len(bh) >= 2 and c["scale"] is not None:  # (the head is 2 * scale_gat_dim wide, model.py:499; BatchNorm needs two rows)
+        if not hasattr(m, "fc1"):                # (model.py builds the head on demand, model_bce.py in its constructor)
+            torch.manual_seed(value_seed + 5)
+            m.initialize_MLP()
+            m.to(gpu_device)
+        params_mlp = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if k != "A_in"}
+        m.train()
+        m.zero_grad(set_to_none=True)
+        out = m(*dev(bh, bp), device=gpu_device, mode="mlp")
+        weights = torch.linspace(-1.0, 1.0, len(bh)).reshape(-1, 1)
+        (out * weights.to(gpu_device)).sum().backward()
+        m.eval()
+
+        def mlp_loss(q, a, nu, tx):
+            q = dict(q)                          # (the running statistics are updated in place: every evaluation from a copy)
+            for k in list(q):
+                if "running_" in k or "num_batches" in k:
+                    q[k] = q[k].clone()
+            return (O.mlp_head(q, O.gat_embeddings(q, cfg, a, nu, tx), bh, bp, training=True) * weights.to(a.dtype)).sum()
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in params_mlp.items()}
+        q = dict(p)
+        for k in list(q):
+            if "running_" in k or "num_batches" in k:
+                q[k] = q[k].clone()
+        want = O.mlp_head(q, O.gat_embeddings(q, cfg, a_in, num, txt), bh, bp, training=True)
+        (want * weights).sum().backward()
+        assert float((out.detach().cpu() - want.detach()).abs().max()) <= 1e-4, f"mlp head output, case {seed}"
+        close_grads(m.named_parameters(), p, in_f64(mlp_loss, params_mlp), f"mlp head, case {seed}",
+                    in_f32_device(mlp_loss, params_mlp))
 
     # ---- attention refresh (the reference cannot add embeddings of different widths either, model.py:441)
     hd, td, rd = dev(*(torch.from_numpy(x) for x in (h, t, r)))

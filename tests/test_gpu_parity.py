@@ -1395,6 +1395,38 @@ def test_pruning_falls_back_when_the_frontier_is_large(L, gpu_device):
     np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
 
 
+def test_pruned_step_on_a_batch_whose_rows_have_no_edges(L, O, gpu_device):
+    """prune_to_batch with a batch made of entities that are nobody's head (found by the randomised sweep, seed 6217: 9 000
+    entities / 9 000 triples, a batch of one): the compact sub-structures hold rows and no entries; forward and backward run,
+    and loss and gradients equal the unpruned step's."""
+    from literalkg_amd import io
+    n, dim = 400, 32
+    rng = np.random.default_rng(4)
+    h, t, r = rng.integers(200, n, 1500), rng.integers(0, n, 1500), rng.integers(0, 3, 1500)      # heads among 200..399 only
+    trip = np.unique(np.stack([h, r, t], 1), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=16, n_conv_layers=2, aggregation_type="gcn", scale_gat_dim=24,
+                        use_num_lit=True, device=gpu_device)
+    torch.manual_seed(0)
+    m = L.LiteralKG(cfg, n, 3, io.initial_a_in(n, h, t, r), torch.rand(n, 2), None).to(gpu_device).eval()
+    ids = [torch.tensor(x, device=gpu_device) for x in ([3, 3], [0, 1], [7, 11], [19, 5])]          # all below 200: no out-edges
+    res = {}
+    for prune in (True, False):
+        m.prune_to_batch = prune
+        out = []
+        for mode, args in (("pre_training", ids), ("fine_tuning", [ids[0], ids[2], ids[3]])):
+            m.zero_grad(set_to_none=True)
+            loss = m(*args, device=gpu_device, mode=mode)
+            loss.backward()
+            out.append((float(loss.detach()), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}))
+        res[prune] = out
+    for (lp, gp), (ld, gd) in zip(res[True], res[False]):
+        assert abs(lp - ld) <= 1e-6 * max(1.0, abs(ld))
+        assert gp.keys() == gd.keys()
+        for k in gd:
+            torch.testing.assert_close(gp[k], gd[k], rtol=1e-4, atol=1e-7, msg=k)
+
+
 def test_gin_ignores_prune_flag(L, gpu_device):
     gd = load_golden("encoder_gin_l2")
     m = _build_model(L, gd, gpu_device, "transr")
