@@ -181,6 +181,11 @@ def _act(x: torch.Tensor) -> torch.Tensor:
     return F.leaky_relu(x, LEAKY_SLOPE)
 
 
+def _relu(x: torch.Tensor) -> torch.Tensor:
+    """the MLP head's activation (model.py:508-515); a function of its own so that tests can watch its inputs"""
+    return torch.relu(x)
+
+
 def _ln(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[1],), p[name + ".weight"], p[name + ".bias"], LN_EPS)
 
@@ -370,7 +375,7 @@ def mlp_head(p: Params, gat: torch.Tensor, head_ids, tail_ids, training: bool = 
     buffers in ``p`` are updated in place like nn.BatchNorm1d does)."""
     x = torch.cat([gat[head_ids], gat[tail_ids]], dim=1)
     for fc, bn in (("fc1", "norm1"), ("fc2", "norm2")):
-        x = torch.relu(F.linear(x, p[fc + ".weight"], p[fc + ".bias"]))
+        x = _relu(F.linear(x, p[fc + ".weight"], p[fc + ".bias"]))
         x = F.batch_norm(x, p[bn + ".running_mean"], p[bn + ".running_var"], p[bn + ".weight"], p[bn + ".bias"],
                          training, 0.1, 1e-5)
     return torch.sigmoid(F.linear(x, p["fc3.weight"], p["fc3.bias"]))

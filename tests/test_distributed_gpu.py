@@ -165,6 +165,10 @@ def _sweep_worker(rank, world, port, seeds, q):
             scheme = ["rows", "features"][int(rng.integers(2))]
             sparse = ["auto", "always", "never"][int(rng.integers(3))]
             partition = [None, "rows", "entries"][int(rng.integers(3))]
+            force = os.environ.get("LKG_FUZZ_SHARDED_FORCE")     # "scheme,exchange,partition" (replaying a case with them changed)
+            if force:
+                scheme, sparse, partition = force.split(",")
+                partition = None if partition == "None" else partition
             n, n_rel = min(c["n"], 20_000), c["n_rel"]
             h, t, r = make_kg(n, min(c["e"], 8 * n), c["skew"], seed=seed)
             r = np.random.default_rng(seed + 1).integers(0, n_rel, len(r))
@@ -193,6 +197,7 @@ def _sweep_worker(rank, world, port, seeds, q):
                                                  sparse_backward=sparse, partition=partition).eval()
                 worst = 0.0
                 what = (seed, scheme, sparse, partition, c)
+                kept = {}                        # (mode, parameter) -> (sharded gradient, single gradient, scale), for the arbiter below
                 for mode, args in (("pre_training", (bh, br, bp, bn)), ("fine_tuning", (bh, bp, bn))):
                     full.zero_grad(set_to_none=True)
                     m.zero_grad(set_to_none=True)
@@ -203,6 +208,9 @@ def _sweep_worker(rank, world, port, seeds, q):
                     m.sync_gradients()
                     assert abs(float(got.detach()) - float(want.detach())) <= 2e-5 * max(1.0, abs(float(want.detach()))), (mode, what, float(got.detach()), float(want.detach()))
                     ref = dict(full.named_parameters())
+                    # (a parameter whose gradient is 1e-4 of the model's largest is below the fp32 noise of the sums that produce it --
+                    # bi-interaction over xavier-sized embeddings: 1e-9 next to 1e-4 -- and is compared on that scale)
+                    largest = max(float(v.grad.abs().max()) for v in ref.values() if v.grad is not None and not v.grad.is_sparse)
                     for k, p in m.local.named_parameters():
                         if p.grad is None or k == "A_in":
                             continue
@@ -212,12 +220,48 @@ def _sweep_worker(rank, world, port, seeds, q):
                             continue
                         if k == "entity_embed.weight":
                             w = w[m.part.lo:m.part.hi]
-                        scale = float(ref[k].grad.abs().max()) + 1e-30
-                        worst = max(worst, float((p.grad - w).abs().max()) / scale if w.numel() else 0.0)
+                        scale = max(float(ref[k].grad.abs().max()), 1e-4 * largest) + 1e-30
+                        dist_k = float((p.grad - w).abs().max()) / scale if w.numel() else 0.0
+                        if os.environ.get("LKG_FUZZ_SHARDED_REPORT") and dist_k > 1e-4:
+                            print(f"  rank {rank} {mode} {k}: {dist_k:.2e} of {scale:.3g}", flush=True)
+                        worst = max(worst, dist_k)
+                        kept[mode, k] = (p.grad.detach().cpu(), w.detach().cpu(), scale)
                 # every rank takes the same decision
                 flag = torch.tensor([worst])
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 if float(flag) < 2e-3:
+                    break
+                # Two fp32 evaluations that sum in different orders (row blocks reduced across ranks against one pass) are being
+                # compared: where the configuration is ill-conditioned in fp32 (residual layers, tests/test_gpu_fuzz.py) they differ
+                # by what either differs from exact arithmetic.  The oracle in float64 arbitrates: the sharded gradient may be no
+                # further from it than 10 x the single module's is.
+                p64 = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point())
+                       for k, v in state.items() if k != "A_in"}
+                dd = lambda x: None if x is None else x.double()
+                a64, b_ = a_in.double(), [x.cpu() for x in (bh, br, bp, bn)]
+                arbiter = 0.0
+                for mode in ("pre_training", "fine_tuning"):
+                    for v in p64.values():
+                        v.grad = None
+                    if mode == "pre_training":
+                        O.pre_training_loss(p64, cfg, a64, *b_, num=dd(num), txt=dd(txt), form=c["scoring"]).backward()
+                    else:
+                        O.prediction_loss(cfg, O.gat_embeddings(p64, cfg, a64, dd(num), dd(txt)), b_[0], b_[2], b_[3]).backward()
+                    for (mode_k, k), (g_sh, g_one, scale) in kept.items():
+                        if mode_k != mode:
+                            continue
+                        truth = p64[k].grad
+                        if k == "entity_embed.weight":
+                            truth = truth[m.part.lo:m.part.hi]
+                        noise = float((g_one.double() - truth).abs().max()) / scale if truth.numel() else 0.0
+                        mine = float((g_sh.double() - truth).abs().max()) / scale if truth.numel() else 0.0
+                        if mine > max(2e-3, 10 * noise):
+                            arbiter = max(arbiter, mine)
+                            if rank == 0:
+                                print(f"  {mode} {k}: sharded {mine:.2e} from float64, single {noise:.2e}", flush=True)
+                flag = torch.tensor([arbiter])
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if float(flag) == 0.0:
                     break
                 assert attempt < 2, ("gradients differ on every draw of the values", float(flag), what)
             # the inference heads: scores of the sharded module == the single module's
@@ -246,7 +290,8 @@ def test_sharded_module_equals_the_single_module_on_drawn_configurations(gpu_dev
     graph, batch), with a drawn scheme ("rows" / "features"), backward exchange ("auto" / "always" / "never") and row
     partition: the row-sharded module on `world` ranks (one GPU, gloo transport, the real kernels) against the single module
     on the same device -- pre-training and fine-tuning loss, every gradient (the entity table by this rank's rows, the
-    replicated weights after sync_gradients), link scores.  LKG_FUZZ_SHARDED_CASES cases per world (default 20)."""
+    replicated weights after sync_gradients; within 2e-3 of the parameter's largest gradient entry, or of 1e-4 of the model's -- or, in
+    configurations that are ill-conditioned in fp32, no further from the float64 oracle than 10 x the single module is), link scores.  LKG_FUZZ_SHARDED_CASES cases per world (default 20)."""
     import __graft_entry__ as ge
     ge.build()
     k = int(os.environ.get("LKG_FUZZ_SHARDED_CASES", "20"))
