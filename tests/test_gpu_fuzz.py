@@ -3,6 +3,7 @@ The hand-picked parity cases of test_gpu_parity.py pin the families; this sweep 
 behind gates, one relation, batches of one, row-sparse machinery on or off, pruning on or off) and checks, per case,
    the pre-training loss, the propagated table and every parameter gradient,
    the fine-tuning loss and its gradients, the MLP head in training mode (output and gradients),
+   a training-mode step with message dropout: the row-sparse backward machinery against the dense backward (large graphs),
    the link scores (calc_score) and the attention refresh,
 each against oracle/literalkg_oracle.py on the same seeded inputs (1e-4 of the largest entry on values, 2e-3 on gradients --
 the tolerances of the hand-picked cases; where a drawn configuration is ill-conditioned in fp32 the oracle is also evaluated
@@ -330,6 +331,35 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
         within_reference_noise(out.detach().cpu(), want.detach(), out64, 1e-4, f"mlp head output, case {seed}")
         close_grads(m.named_parameters(), p, in_f64(mlp_loss, params_mlp), f"mlp head, case {seed}",
                     in_f32_device(mlp_loss, params_mlp))
+
+    # ---- training mode with message dropout: the row-sparse backward machinery against the dense backward of the same model
+    # (no oracle: the masks come from this package's generator; from 16 384 rows on the machinery is active)
+    if n >= 16384 and not c["prune"]:
+        from literalkg_amd import ops as _ops
+        for layer in m.aggregator_layers:
+            layer.dropout = 0.2
+        m.train()
+
+        def step(sparse):
+            m.zero_grad(set_to_none=True)
+            m._table_grad_stays_inside = (lambda: m.gat_rows is None) if sparse else (lambda: False)
+            torch.manual_seed(value_seed + 11)           # (the dropout seeds follow torch's CPU generator)
+            loss_ = m(*dev(bh, br, bp, bn), device=gpu_device, mode="pre_training")
+            loss_.backward()
+            return float(loss_.detach()), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None and k != "A_in"}
+        try:
+            (l_s, g_s), (l_d, g_d) = step(True), step(False)
+        finally:
+            del m._table_grad_stays_inside
+            _ops._RowScratch._tables.clear()
+            for layer in m.aggregator_layers:
+                layer.dropout = 0.0
+            m.eval()
+        assert l_s == l_d and np.isfinite(l_s), (f"training-mode loss, case {seed}", l_s, l_d)
+        assert g_s.keys() == g_d.keys()
+        for k in g_d:
+            scale_k = float(g_d[k].abs().max()) + 1e-30
+            assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-5 * scale_k + 1e-12, (f"row-sparse against dense backward, case {seed}", k)
 
     # ---- attention refresh (the reference cannot add embeddings of different widths either, model.py:441)
     hd, td, rd = dev(*(torch.from_numpy(x) for x in (h, t, r)))
