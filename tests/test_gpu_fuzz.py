@@ -373,6 +373,30 @@ def run_case(L, O, gpu_device, c, seed, value_seed):
     got_a = m.A_in.data.cpu()
     assert torch.equal(got_a.indices(), ref_a.indices())
     torch.testing.assert_close(got_a.values(), ref_a.values(), rtol=1e-4, atol=1e-6)
+    # ... and over a SUBSET of the relations: the reference visits the listed relations only (model.py:451), the triples of the
+    # others are not part of the refreshed matrix; then the forward runs on it
+    if n_rel > 1:
+        sub_rng = np.random.default_rng(value_seed + 23)
+        listed = sorted(sub_rng.choice(n_rel, max(1, n_rel // 2), replace=False).tolist())
+        keep = np.isin(r, listed)
+        m(hd, td, rd, listed, device=gpu_device, mode="update_att")
+        got_b = m.A_in.data.cpu().coalesce()
+        if keep.any():
+            ref_b = O.attention_refresh(n, params["entity_embed.weight"], params["relation_embed.weight"],
+                                        torch.from_numpy(h[keep]), torch.from_numpy(t[keep]), torch.from_numpy(r[keep])).coalesce()
+            assert torch.equal(got_b.indices(), ref_b.indices()), f"refresh over relations {listed}, case {seed}"
+            torch.testing.assert_close(got_b.values(), ref_b.values(), rtol=1e-4, atol=1e-6)
+            with torch.no_grad():
+                got_s = m.calc_score(*dev(bh[:20], bp[:30]))
+            gat_b = O.gat_embeddings(params, cfg, ref_b, num, txt)
+            within_reference_noise(got_s.cpu(), O.link_scores(gat_b, bh[:20], bp[:30]),
+                                   lambda: O.link_scores(O.gat_embeddings({k: v.double() if v.is_floating_point() else v
+                                                                           for k, v in params.items()}, cfg, ref_b.double(),
+                                                                          None if num is None else num.double(),
+                                                                          None if txt is None else txt.double()), bh[:20], bp[:30]),
+                                   1e-4, f"link scores on the subset's matrix, case {seed}")
+        else:
+            assert got_b._nnz() == 0
 
 
 # ============================================================================= the fused SpMM entry point, option by option
