@@ -229,7 +229,9 @@ def _sweep_worker(rank, world, port, seeds, q):
                 # every rank takes the same decision
                 flag = torch.tensor([worst])
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                if float(flag) < 2e-3:
+                # (three or more residual layers: the family that amplifies rounding layer by layer, tests/test_gpu_fuzz.py -- 2e-2)
+                tol = 2e-2 if (c["residual"] and c["layers"] >= 3) else 2e-3
+                if float(flag) < tol:
                     break
                 # Two fp32 evaluations that sum in different orders (row blocks reduced across ranks against one pass) are being
                 # compared: where the configuration is ill-conditioned in fp32 (residual layers, tests/test_gpu_fuzz.py) they differ
@@ -255,7 +257,7 @@ def _sweep_worker(rank, world, port, seeds, q):
                             truth = truth[m.part.lo:m.part.hi]
                         noise = float((g_one.double() - truth).abs().max()) / scale if truth.numel() else 0.0
                         mine = float((g_sh.double() - truth).abs().max()) / scale if truth.numel() else 0.0
-                        if mine > max(2e-3, 10 * noise):
+                        if mine > max(tol, 10 * noise):
                             arbiter = max(arbiter, mine)
                             if rank == 0:
                                 print(f"  {mode} {k}: sharded {mine:.2e} from float64, single {noise:.2e}", flush=True)
