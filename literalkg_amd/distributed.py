@@ -141,8 +141,9 @@ class HipKernels:
         m = int(out_rowptr[-1])                                    # (host sync: the frontier's size decides the shapes)
         out_col = torch.empty(max(m, 1), dtype=torch.int32, device=rows.device)
         out_val = torch.empty(max(m, 1), dtype=torch.float32, device=rows.device)
-        N.call("lkg_csr_extract_rows", rows.numel(), N.ptr(rows), N.ptr(rowptr), N.ptr(col), N.ptr(val),
-               N.ptr(out_rowptr), N.ptr(out_col), N.ptr(out_val), ops._stream())
+        if m:
+            N.call("lkg_csr_extract_rows", rows.numel(), N.ptr(rows), N.ptr(rowptr), N.ptr(col), N.ptr(val),
+                   N.ptr(out_rowptr), N.ptr(out_col), N.ptr(out_val), ops._stream())
         tails, pos = torch.unique(out_col[:m].long(), return_inverse=True)
         gc = ops.gather_rows_range(grad, rows - row0, 0, grad.shape[0])
         buf = torch.zeros((tails.numel(), d), dtype=torch.float32, device=grad.device)

@@ -756,7 +756,7 @@ class _AggregateKeep(Function):
         ctx.set_materialize_grads(False)
         copy = None
         kept = ego
-        if keep_dst is not None and (keep_dst.data_ptr() != ego.data_ptr() or keep_dst.stride() != ego.stride()):
+        if keep_dst is not None and not _same_view(keep_dst, ego):
             copy, kept = (ego, keep_dst), keep_dst
         rm = torch.empty(g.n, dtype=torch.float32, device=ego.device) if _wants_rowmax(g.n) else None
         side = spmm_raw(g.rowptr, g.col, val, ego, g.n, long_rows=g.long_rows(False),
@@ -1252,6 +1252,13 @@ class CatBuffer:
         return self.buf[:, self.offsets[k]:self.offsets[k + 1]]
 
 
+def _same_view(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Do a and b address the same elements?  (A dimension of size 1 may carry any stride: a one-row view of a wider buffer
+    reports the buffer's row stride, the same row produced in place may report its own width.)"""
+    return (a.data_ptr() == b.data_ptr() and a.shape == b.shape
+            and all(sa == sb for sa, sb, n_ in zip(a.stride(), b.stride(), a.shape) if n_ > 1))
+
+
 class _AssembleCat(Function):
     @staticmethod
     def forward(ctx, holder: CatBuffer, pending, *parts):
@@ -1259,7 +1266,7 @@ class _AssembleCat(Function):
             s = holder.slot(k)
             if k in pending:                     # left unwritten on purpose: the caller completes it on demand (fill_slot)
                 continue
-            if p.data_ptr() != s.data_ptr() or p.stride() != s.stride():
+            if not _same_view(p, s):
                 s.copy_(p)                       # a part that was not produced in place (e.g. the raw entity table)
         ctx.offsets = holder.offsets
         # An ALIAS of the buffer, not the buffer itself: the parts are views of holder.buf, and a consumer below may have

@@ -64,8 +64,9 @@ def build_batch_subgraph(graph: KGStructure, val: torch.Tensor, ids: torch.Tenso
         m = int(out_rowptr[-1])                                   # the one host sync per layer
         out_col = torch.empty(max(m, 1), dtype=torch.int32, device=rk.device)
         out_val = torch.empty(max(m, 1), dtype=torch.float32, device=rk.device)
-        N.call("lkg_csr_extract_rows", rk.numel(), N.ptr(rk), N.ptr(rp), N.ptr(graph.col), N.ptr(val),
-               N.ptr(out_rowptr), N.ptr(out_col), N.ptr(out_val), ops._stream())
+        if m:                                    # (no entry to extract: an empty matrix, or rows that are nobody's head)
+            N.call("lkg_csr_extract_rows", rk.numel(), N.ptr(rk), N.ptr(rp), N.ptr(graph.col), N.ptr(val),
+                   N.ptr(out_rowptr), N.ptr(out_col), N.ptr(out_val), ops._stream())
         col_ids = out_col[:m].long()
         prev = torch.unique(torch.cat([rk, col_ids]))
         rows[k - 1] = prev

@@ -2382,3 +2382,77 @@ def test_deferred_slot0_copy_is_made_on_demand(L, ops, O, gpu_device):
     for k, v in m.named_parameters():
         if v.grad is not None:
             assert float((v.grad - g_sparse[k]).abs().max()) <= 5e-5 * (float(v.grad.abs().max()) + 1e-30), k
+
+
+# ----------------------------------------------------------------------------- degenerate but legal shapes
+@pytest.mark.parametrize("agg", ["gcn", "graphsage", "bi-interaction", "gin"])
+@pytest.mark.parametrize("prune", [False, True])
+def test_degenerate_shapes_against_the_oracle(L, O, gpu_device, agg, prune):
+    """Shapes the reference's code tolerates and a randomised sweep rarely draws: a graph of ONE entity with a self-loop, a
+    batch whose ids are all the same entity, a refresh over relations that match no triple (the matrix becomes empty and every
+    aggregation returns zero rows) followed by the losses on that empty matrix -- full-graph and pruned."""
+    from literalkg_amd import io
+    torch.manual_seed(3)
+    # ---- one entity, one self-loop
+    cfg = O.default_cfg(embed_dim=8, relation_dim=8, conv_dim=8, n_conv_layers=2, aggregation_type=agg, mlp_hidden_dim=8,
+                        device=gpu_device)
+    one = np.zeros(1, np.int64)
+    a_in = io.initial_a_in(1, one, one, one)
+    m = L.LiteralKG(cfg, 1, 1, a_in)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
+    m.to(gpu_device).eval()
+    m.prune_to_batch = prune
+    z = torch.zeros(2, dtype=torch.long)
+    loss = m(*[z.to(gpu_device)] * 4, device=gpu_device, mode="pre_training")
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+    want = O.pre_training_loss(p, cfg, a_in, z, z, z, z)
+    np.testing.assert_allclose(float(loss.detach()), float(want.detach()), rtol=1e-5)
+    loss.backward()
+    want.backward()
+    for k, v in m.named_parameters():
+        if v.grad is not None and k != "A_in":
+            torch.testing.assert_close(v.grad.cpu(), p[k].grad, rtol=1e-3, atol=1e-6, msg=k)
+
+    # ---- 50 entities; every batch id the same entity; then a refresh over a relation nobody uses
+    n, dim = 50, 12
+    rng = np.random.default_rng(1)
+    h, t, r = rng.integers(0, n, 200), rng.integers(0, n, 200), rng.integers(0, 2, 200)           # relations 0 and 1 of 4
+    trip = np.unique(np.stack([h, r, t], 1), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=2, aggregation_type=agg, mlp_hidden_dim=8,
+                        use_num_lit=True, scale_gat_dim=10, device=gpu_device)
+    num = torch.rand(n, 2)
+    a_in = io.initial_a_in(n, h, t, r)
+    m = L.LiteralKG(cfg, n, 4, a_in, num, None)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
+    m.to(gpu_device).eval()
+    m.prune_to_batch = prune
+    same = torch.full((6,), 7, dtype=torch.long)
+    rel = torch.zeros(6, dtype=torch.long)
+
+    def both(a_ref):
+        out = []
+        for mode, args, ref in (("pre_training", (same, rel, same, same), lambda q: O.pre_training_loss(q, cfg, a_ref, same, rel, same, same, num=num)),
+                                ("fine_tuning", (same, same, same), lambda q: O.prediction_loss(cfg, O.gat_embeddings(q, cfg, a_ref, num, None), same, same, same))):
+            m.zero_grad(set_to_none=True)
+            got = m(*[x.to(gpu_device) for x in args], device=gpu_device, mode=mode)
+            got.backward()
+            q = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+            want_ = ref(q)
+            want_.backward()
+            np.testing.assert_allclose(float(got.detach()), float(want_.detach()), rtol=1e-5, err_msg=mode)
+            for k, v in m.named_parameters():
+                if v.grad is not None and k != "A_in" and q[k].grad is not None:
+                    torch.testing.assert_close(v.grad.cpu(), q[k].grad, rtol=2e-3, atol=1e-6, msg=f"{mode} {k}")
+            out.append(float(got.detach()))
+        return out
+    both(a_in)
+    dev = lambda x: torch.from_numpy(x).to(gpu_device)
+    m(dev(h), dev(t), dev(r), [3], device=gpu_device, mode="update_att")                         # relation 3: no triple
+    empty = m.A_in.data.cpu().coalesce()
+    assert empty._nnz() == 0 and tuple(empty.shape) == (n, n)
+    both(torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.long), torch.zeros(0), (n, n)).coalesce())
+    with torch.no_grad():
+        s = m.calc_score(same[:2].to(gpu_device), torch.arange(5, device=gpu_device))
+    gat = O.gat_embeddings(params, cfg, torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.long), torch.zeros(0), (n, n)).coalesce(), num, None)
+    torch.testing.assert_close(s.cpu(), O.link_scores(gat, same[:2], torch.arange(5)), rtol=1e-4, atol=1e-5)
