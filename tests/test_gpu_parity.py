@@ -399,7 +399,7 @@ def test_gemm_split_k_and_slices(ops, gpu_device):
 
 
 # ----------------------------------------------------------------------------- K5 / K6 epilogues
-@pytest.mark.parametrize("d,n", [(8, 257), (30, 257), (32, 257), (64, 257), (100, 257), (128, 257), (132, 257), (256, 257),
+@pytest.mark.parametrize("d,n", [(1, 257), (2, 257), (3, 257), (5, 257), (8, 257), (30, 257), (32, 257), (64, 257), (100, 257), (128, 257), (132, 257), (256, 257),
                                  (300, 257), (1024, 257),
                                  (8, 5001), (32, 5001), (64, 5001), (100, 5001), (128, 5001)])      # several rows per wave, both ways
 @pytest.mark.parametrize("with_norm", [True, False])
@@ -2456,3 +2456,40 @@ def test_degenerate_shapes_against_the_oracle(L, O, gpu_device, agg, prune):
         s = m.calc_score(same[:2].to(gpu_device), torch.arange(5, device=gpu_device))
     gat = O.gat_embeddings(params, cfg, torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.long), torch.zeros(0), (n, n)).coalesce(), num, None)
     torch.testing.assert_close(s.cpu(), O.link_scores(gat, same[:2], torch.arange(5)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("layers,dim,residual", [(0, 6, False), (1, 2, False), (2, 3, True), (1, 5, True)])
+def test_degenerate_architectures_against_the_oracle(L, O, gpu_device, layers, dim, residual):
+    """No aggregation layer at all (the encoder is the gate's output alone), two- and three-wide embeddings, a single residual
+    layer (no stacked h0 projection): loss and gradients against the oracle, full-graph and pruned.  (One-wide embeddings are
+    left out: LayerNorm over one element returns its bias, zero at initialisation, F.normalize divides that by its 1e-12
+    clamp, and the reference's gradients become 1e12 x rounding dust -- 3.6e5 where exact arithmetic, and this package, give 0.)"""
+    from literalkg_amd import io
+    from literalkg_amd.synth import make_batch
+    n = 60
+    rng = np.random.default_rng(layers * 10 + dim)
+    trip = np.unique(np.stack([rng.integers(0, n, 300), rng.integers(0, 3, 300), rng.integers(0, n, 300)], 1), axis=0)
+    h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+    cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=layers, aggregation_type="gcn",
+                        use_residual=residual, use_txt_lit=True, txt_lit_dim=3, device=gpu_device)
+    torch.manual_seed(layers + dim)
+    txt = torch.randn(n, 3)
+    a_in = io.initial_a_in(n, h, t, r)
+    m = L.LiteralKG(cfg, n, 3, a_in, None, txt)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
+    m.to(gpu_device).eval()
+    bh, br, bp, bn = (torch.from_numpy(x) for x in make_batch(n, 9, 2, seed=3))
+    br = br % 3
+    for prune in (False, True):
+        m.prune_to_batch = prune
+        m.zero_grad(set_to_none=True)
+        loss = m(*[x.to(gpu_device) for x in (bh, br, bp, bn)], device=gpu_device, mode="pre_training")
+        loss.backward()
+        p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+        want = O.pre_training_loss(p, cfg, a_in, bh, br, bp, bn, txt=txt)
+        want.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(want.detach()), rtol=1e-5)
+        for k, v in m.named_parameters():
+            if v.grad is not None and k != "A_in" and p[k].grad is not None:
+                torch.testing.assert_close(v.grad.cpu(), p[k].grad, rtol=2e-3, atol=1e-6,
+                                           msg=lambda s_: f"prune={prune} {k}: {s_} got {v.grad.cpu().flatten()[:4]} want {p[k].grad.flatten()[:4]}")
