@@ -145,10 +145,22 @@ def call(name, *args):
         raise LkgError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
 
 
+_empty_stand_ins = {}
+
+
 def ptr(t):
-    """Raw pointer of a tensor / numpy array (None -> NULL)."""
+    """Raw pointer of a tensor / numpy array (None -> NULL).  An EMPTY tensor (a rank without rows, a structure without
+    entries) has a null data pointer of its own; the entry points take NULL to mean "operand absent", so an empty operand is
+    handed over as the address of a small per-device stand-in buffer instead -- never dereferenced, its extent being zero."""
     if t is None:
         return None
     if hasattr(t, "data_ptr"):
-        return t.data_ptr()
+        p = t.data_ptr()
+        if p == 0 and t.numel() == 0:
+            key = str(t.device)
+            if key not in _empty_stand_ins:
+                import torch
+                _empty_stand_ins[key] = torch.zeros(64, dtype=torch.float32, device=t.device)
+            p = _empty_stand_ins[key].data_ptr()
+        return p
     return t.ctypes.data

@@ -1239,8 +1239,8 @@ extern "C" int lkg_eltwise_f32(int32_t op, int64_t n, int32_t d, const float *a,
                                int64_t ldb, float alpha, float beta, float *out, int64_t ldo, void *stream) {
     LKG_REQUIRE(op >= 0 && op <= 3, "lkg_eltwise_f32: unknown op %d", op);
     LKG_REQUIRE(n >= 0 && d > 0 && lda >= d && ldo >= d && (!b || ldb >= d), "lkg_eltwise_f32: bad sizes");
+    if (n == 0) return LKG_OK;             // (a rank without rows: its tensors are empty and their pointers null)
     LKG_REQUIRE(b || (op != 1 && op != 3), "lkg_eltwise_f32: op %d needs two operands", op);
-    if (n == 0) return LKG_OK;
     LKG_REQUIRE(a && out, "lkg_eltwise_f32: null pointer");
     const bool vec = d % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (!b || ldb % 4 == 0) && lkg_aligned16(a) &&
                      lkg_aligned16(out) && (!b || lkg_aligned16(b));

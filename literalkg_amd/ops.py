@@ -182,7 +182,7 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
     if cdst is not None and (cdst.stride(1) != 1 or cdst.shape != (n_rows, d)):
         raise ValueError("spmm_raw: copy destination must be an n_rows x d view with unit column stride")
     N.call("lkg_spmm_csr_fused_f32", n_rows, d, N.ptr(rowptr), N.ptr(col), N.ptr(val),
-           x.data_ptr() - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
+           N.ptr(x) - 4 * x_row_offset * _ld(x), _ld(x), N.ptr(out), _ld(out), N.ptr(add_self),
            _ld(add_self) if add_self is not None else 0, N.ptr(add2 if bias is None else bias),
            _ld(add2) if add2 is not None else 0, N.ptr(add2_rows if add2 is not None else None), N.ptr(csrc), _ld(csrc) if csrc is not None else 0, N.ptr(cdst), _ld(cdst) if cdst is not None else 0,
            N.ptr(rowmax), (x_rows.data_ptr() - x_row_offset) if x_rows is not None else None,

@@ -313,3 +313,88 @@ def test_sharded_module_equals_the_single_module_on_drawn_configurations(gpu_dev
     for r, msg in bad:
         print(f"---- rank {r}\n{msg}")
     assert not bad, f"{len(bad)} of {world} ranks failed (their tracebacks are in the captured output)"
+
+
+# ----------------------------------------------------------------------------- degenerate shapes under sharding
+def _degenerate_worker(rank, world, port, scheme, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import literalkg_amd as L
+        from literalkg_amd import distributed as D, io
+        from oracle import literalkg_oracle as O
+        for n, agg, sparse in ((1, "gcn", "auto"), (2, "graphsage", "always"), (40, "bi-interaction", "never"), (40, "gcn", "always")):
+            rng = np.random.default_rng(n)
+            trip = np.unique(np.stack([rng.integers(0, n, 5 * n), rng.integers(0, 2, 5 * n), rng.integers(0, n, 5 * n)], 1), axis=0)
+            h, r, t = trip[:, 0].copy(), trip[:, 1].copy(), trip[:, 2].copy()
+            cfg = O.default_cfg(embed_dim=8, relation_dim=8, conv_dim=8, n_conv_layers=2, aggregation_type=agg, use_num_lit=True,
+                                scale_gat_dim=6, device=dev)
+            torch.manual_seed(n)
+            num = torch.rand(n, 2)
+            full = L.LiteralKG(cfg, n, 4, io.initial_a_in(n, h, t, r), num, None)
+            state = {k: v.detach().clone() for k, v in full.state_dict().items()}
+            full.to(dev).eval()
+            m = D.ShardedLiteralKG.from_full(cfg, n, 4, state, num, None, scheme=scheme, device=dev, sparse_backward=sparse).eval()
+            same = torch.full((4,), n - 1, dtype=torch.long, device=dev)        # every batch id the same entity
+            rel = torch.zeros(4, dtype=torch.long, device=dev)
+            hd, td, rd = (torch.from_numpy(x).to(dev) for x in (h, t, r))
+
+            def compare(tag):
+                for mode, args in (("pre_training", (same, rel, same, same)), ("fine_tuning", (same, same, same))):
+                    full.zero_grad(set_to_none=True)
+                    m.zero_grad(set_to_none=True)
+                    want = full(*args, device=dev, mode=mode)
+                    want.backward()
+                    got = m(*args, device=dev, mode=mode)
+                    got.backward()
+                    m.sync_gradients()
+                    assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * max(1.0, abs(float(want.detach()))), (tag, mode, n, agg)
+                    ref = dict(full.named_parameters())
+                    for k, p in m.local.named_parameters():
+                        if p.grad is None or k == "A_in" or ref[k].grad is None:
+                            continue
+                        w = ref[k].grad[m.part.lo:m.part.hi] if k == "entity_embed.weight" else ref[k].grad
+                        torch.testing.assert_close(p.grad, w, rtol=2e-3, atol=1e-6, msg=f"{tag} {mode} n={n} {agg} {k}")
+            compare("loader's matrix")
+            for mod in (full, m):                                               # a refresh over a relation no triple carries
+                mod(hd, td, rd, [3], device=dev, mode="update_att")
+            compare("empty matrix")
+            for mod in (full, m):                                               # ... and back to a populated one
+                mod(hd, td, rd, [0, 1], device=dev, mode="update_att")
+            compare("refreshed matrix")
+            with torch.no_grad():
+                a, b = m.local.calc_score(same[:1], same[:2]), full.calc_score(same[:1], same[:2])
+                assert float((a - b).abs().max()) <= 1e-4 * (float(b.abs().max()) + 1e-30)
+        q.put((rank, "ok"))
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-4000:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,scheme", [(2, "rows"), (2, "features"), (3, "rows")])
+def test_sharded_module_on_degenerate_shapes(gpu_device, world, scheme):
+    """One entity on two ranks (a rank without rows), two entities, every batch id the same entity, a refresh over a relation
+    that no triple carries (an empty matrix on every rank) and back: the sharded module against the single module."""
+    import __graft_entry__ as ge
+    ge.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_degenerate_worker, args=(r, world, port, scheme, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=540) for _ in procs]
+    for p in procs:
+        p.join(60)
+    bad = [(r, msg) for r, msg in res if msg != "ok"]
+    for r, msg in bad:
+        print(f"---- rank {r}\n{msg}")
+    assert not bad, f"{len(bad)} of {world} ranks failed (their tracebacks are in the captured output)"
