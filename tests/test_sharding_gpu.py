@@ -149,3 +149,96 @@ def test_bench_two_rank_rehearsal_starts_its_own_workers(gpu_device):
     st = j["sharded_pre_training_step"]
     assert "error" not in st and st["rows"]["ms_per_step"] > 0 and st["features"]["ms_per_step"] > 0
     assert "note" not in j                                   # no phase was abandoned by the watchdog
+
+
+# ----------------------------------------------------------------------------- drawn shapes of the feature-sharded aggregation
+def _sweep_worker(rank, world, port, seeds, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import literalkg_amd as L
+        from literalkg_amd import ops
+        from literalkg_amd.sharding import FeatureShardedAggregation, shard_bounds
+        from literalkg_amd.synth import make_kg
+        dev = torch.device("cuda", 0)
+        n_done = 0
+        for seed in seeds:
+            rng = np.random.default_rng(seed)
+            pick = lambda xs: xs[int(rng.integers(len(xs)))]
+            n = int(pick([world, 7, 50, 3000, 30_000]))
+            e = int(max(1, n * pick([0.3, 1, 5, 15])))
+            dg = int(pick([3, 4, 8, 16, 32, 64]))           # columns per rank: the scalar path (3) and the 16-byte paths
+            d = dg * world
+            h, t, r = make_kg(n, min(e, n * n), pick(["zipf", "uniform"]), seed=seed)
+            g = L.KGStructure.from_triples(n, h, t, r, device=dev)
+            gen = torch.Generator(device=dev).manual_seed(seed)
+            val = torch.rand(g.nnz, generator=gen, device=dev)
+            x = torch.randn((n, d), generator=gen, device=dev)
+            gx = torch.randn((n, d), generator=gen, device=dev)
+            want_side = ops.spmm_raw(g.rowptr, g.col, val, x, n, long_rows=g.long_rows(False))
+            want_grad = ops.spmm_raw(g.t_rowptr, g.t_col, ops.permute_values(val, g.t_perm), gx, n, long_rows=g.long_rows(True))
+            kind = pick(["entries", "equal", "lopsided"])
+            if kind == "entries":
+                cuts = shard_bounds(g, world)
+            elif kind == "equal":
+                cuts = [min(n, -(-n // world) * i) for i in range(world + 1)]
+            else:                                           # one rank owns (almost) everything, another nothing
+                cuts = [0] + sorted(int(v) for v in rng.choice([0, n // 3, n], world - 1)) + [n]
+            lo, hi = cuts[rank], cuts[rank + 1]
+            what = (seed, world, n, g.nnz, dg, kind, cuts)
+            fs = FeatureShardedAggregation(g, val, rank, world, d, cuts)
+            cols = slice(rank * dg, (rank + 1) * dg)
+            tol = dict(rtol=1e-4, atol=1e-4)
+            panels = lambda tab: torch.stack([tab[lo:hi, i * dg:(i + 1) * dg] for i in range(world)]).contiguous()
+            # the bench's forms: slab forward with the pipelined return exchange, row block -> slab backward in pieces
+            side_slab, block = fs.forward_to_row_block(fs.column_slab(x), pieces=int(pick([1, 2, 4, 7])))
+            torch.testing.assert_close(side_slab, want_side[:, cols], msg=lambda m_: f"forward slab {what}: {m_}", **tol)
+            torch.testing.assert_close(block, panels(want_side), msg=lambda m_: f"forward row block {what}: {m_}", **tol)
+            got = fs.backward_from_row_block(panels(gx), pieces=int(pick([1, 2, 3])))
+            torch.testing.assert_close(got, want_grad[:, cols], msg=lambda m_: f"backward from row block {what}: {m_}", **tol)
+            # the module's form: both exchanges folded into the SpMM, forward and transposed, with and without the self term
+            for transposed, src, want in ((False, x, want_side), (True, gx, want_grad)):
+                plus_self = bool(rng.random() < 0.5)
+                slab_out, out = fs.exchange_aggregate(transposed, block_in=panels(src), plus_self=plus_self,
+                                                      n_batches=pick([None, 1, 2, 5]), pieces=pick([None, 1, 3]))
+                ref = want + src if plus_self else want
+                torch.testing.assert_close(slab_out, ref[:, cols], msg=lambda m_: f"exchange_aggregate slab T={transposed} {what}: {m_}", **tol)
+                torch.testing.assert_close(out, panels(ref), msg=lambda m_: f"exchange_aggregate block T={transposed} {what}: {m_}", **tol)
+            dist.barrier()
+            n_done += 1
+        assert n_done == len(seeds)
+        q.put((rank, "ok"))
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-3000:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_feature_sharded_aggregation_over_drawn_shapes(gpu_device, world):
+    """The exchange forms bench.py times at N > 1 and the module uses (slab forward with the pipelined return exchange, the
+    transpose from a row block in pieces, exchange_aggregate with its incoming sub-ranges and outgoing pieces) on drawn
+    graphs, widths (scalar and 16-byte paths), row cuts (balanced by entries, equal, lopsided with an empty rank), batch and
+    piece counts -- 2, 3 and 4 ranks on the one GPU over gloo, every rank against the single-device product.
+    LKG_FUZZ_FS_CASES cases per world size (default 30)."""
+    import __graft_entry__ as ge
+    ge.build()
+    k = int(os.environ.get("LKG_FUZZ_FS_CASES", "30"))
+    seeds = [51000 + 100 * world + i for i in range(k)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, seeds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=840) for _ in procs]
+    for p in procs:
+        p.join(60)
+    bad = [(r, msg) for r, msg in res if msg != "ok"]
+    for r, msg in bad:
+        print(f"---- rank {r}\n{msg}")
+    assert not bad, f"{len(bad)} of {world} ranks failed (their tracebacks are in the captured output)"
