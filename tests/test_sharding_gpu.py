@@ -158,7 +158,7 @@ def _sweep_worker(rank, world, port, seeds, q):
     try:
         import literalkg_amd as L
         from literalkg_amd import ops
-        from literalkg_amd.sharding import FeatureShardedAggregation, shard_bounds
+        from literalkg_amd.sharding import FeatureShardedAggregation, ShardedAggregation, shard_bounds
         from literalkg_amd.synth import make_kg
         dev = torch.device("cuda", 0)
         n_done = 0
@@ -204,6 +204,28 @@ def _sweep_worker(rank, world, port, seeds, q):
                 ref = want + src if plus_self else want
                 torch.testing.assert_close(slab_out, ref[:, cols], msg=lambda m_: f"exchange_aggregate slab T={transposed} {what}: {m_}", **tol)
                 torch.testing.assert_close(out, panels(ref), msg=lambda m_: f"exchange_aggregate block T={transposed} {what}: {m_}", **tol)
+            # the north star's row-range form: own head rows forward, chunked all-reduce behind the transpose SpMM
+            keep = (h >= lo) & (h < hi)
+            mine = L.KGStructure.from_triples(n, h[keep], t[keep], r[keep], device=dev)
+            rp = g.host("rowptr")
+            val_mine = val[int(rp[lo]):int(rp[hi])].contiguous()
+            assert mine.nnz == val_mine.numel(), what
+            sh = ShardedAggregation(mine, val_mine, lo, hi, n_chunks=int(pick([1, 2, 3, 5])))
+            if hi > lo:
+                torch.testing.assert_close(sh.forward(x), want_side[lo:hi], msg=lambda m_: f"row-range forward {what}: {m_}", **tol)
+            real = dist.all_reduce
+
+            def staged_all_reduce(x_, op=None, group=None, async_op=False):      # gloo moves host memory only
+                hx = x_.cpu()
+                real(hx, op=dist.ReduceOp.SUM, group=group)
+                x_.copy_(hx)
+                return type("W", (), {"wait": lambda self: None})()
+            dist.all_reduce = staged_all_reduce
+            try:
+                grad = sh.backward(gx[lo:hi].contiguous())
+            finally:
+                dist.all_reduce = real
+            torch.testing.assert_close(grad, want_grad, msg=lambda m_: f"row-range backward {what}: {m_}", **tol)
             dist.barrier()
             n_done += 1
         assert n_done == len(seeds)
@@ -221,7 +243,8 @@ def test_feature_sharded_aggregation_over_drawn_shapes(gpu_device, world):
     """The exchange forms bench.py times at N > 1 and the module uses (slab forward with the pipelined return exchange, the
     transpose from a row block in pieces, exchange_aggregate with its incoming sub-ranges and outgoing pieces) on drawn
     graphs, widths (scalar and 16-byte paths), row cuts (balanced by entries, equal, lopsided with an empty rank), batch and
-    piece counts -- 2, 3 and 4 ranks on the one GPU over gloo, every rank against the single-device product.
+    piece counts, and the row-range form with its chunked all-reduce -- 2, 3 and 4 ranks on the one GPU over gloo, every rank
+    against the single-device product.
     LKG_FUZZ_FS_CASES cases per world size (default 30)."""
     import __graft_entry__ as ge
     ge.build()
