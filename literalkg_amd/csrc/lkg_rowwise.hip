@@ -785,8 +785,8 @@ extern "C" int lkg_act_layernorm_bwd_f32(int64_t n, int32_t d, const float *z, i
     LKG_REQUIRE(!row_ids || (sparse_out && n_row_ids >= 0), "lkg_act_layernorm_bwd_f32: a row list needs sparse_out");
     LKG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "lkg_act_layernorm_bwd_f32: dropout probability %g outside [0,1)", drop_p);
     LKG_REQUIRE(n >= 0 && d > 0 && ldz >= d && ldgz >= d, "lkg_act_layernorm_bwd_f32: bad sizes");
+    if (n == 0) return LKG_OK;             // (a rank without rows: empty operands may come as null pointers)
     LKG_REQUIRE(g_y || g_yn, "lkg_act_layernorm_bwd_f32: both upstream gradients are null");
-    if (n == 0) return LKG_OK;
     LKG_REQUIRE(z && gamma && save_mean && save_rstd && g_z && g_gamma && g_beta && (!g_yn || y || beta),
                 "lkg_act_layernorm_bwd_f32: null pointer (g_yn needs y, or beta to recompute it)");
     hipStream_t s = (hipStream_t)stream;
