@@ -286,11 +286,11 @@ def _sweep_worker(rank, world, port, seeds, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,first_seed", [(2, 21000), (3, 22000)])
+@pytest.mark.parametrize("world,first_seed", [(2, 21000), (3, 22000), (4, 23000)])
 def test_sharded_module_equals_the_single_module_on_drawn_configurations(gpu_device, world, first_seed):
     """Configurations drawn like tests/test_gpu_fuzz.py's (aggregator, layers, widths, residual, gate, scale_gat_dim, scoring,
     graph, batch), with a drawn scheme ("rows" / "features"), backward exchange ("auto" / "always" / "never") and row
-    partition: the row-sharded module on `world` ranks (one GPU, gloo transport, the real kernels) against the single module
+    partition: the row-sharded module on `world` = 2, 3, 4 ranks (one GPU, gloo transport, the real kernels) against the single module
     on the same device -- pre-training and fine-tuning loss, every gradient (the entity table by this rank's rows, the
     replicated weights after sync_gradients; within 2e-3 of the parameter's largest gradient entry, or of 1e-4 of the model's -- or, in
     configurations that are ill-conditioned in fp32, no further from the float64 oracle than 10 x the single module is), link scores.  LKG_FUZZ_SHARDED_CASES cases per world (default 20)."""
