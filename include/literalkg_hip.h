@@ -221,8 +221,19 @@ int lkg_edge_softmax_f32(int64_t n_rows, int64_t row_offset, int32_t d, const in
                          float *val_out, float *logits_out, const int32_t *long_rows, int32_t n_long,
                          int32_t long_thresh, int32_t n_rel, void *stream);
 
-/* dst[i] = src[perm[i]]  (attention values into CSC order after a refresh)     */
-int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src, float *dst, void *stream);
+/* dst[i] = src[perm[i]] for i < n  (attention values into CSC order after a refresh, or into the entry order of a part
+ * of the structure).  n_src = the extent of src: an index outside [0, n_src) is not dereferenced and NaN is stored for it,
+ * so an index list that does not belong to src can never make the device read outside src.                       */
+int lkg_permute_f32(int64_t n, const int32_t *perm, int64_t n_src, const float *src, float *dst, void *stream);
+
+/* Structure check (a debugging / hardening aid; no counterpart in the reference, whose torch.sparse tensors validate
+ * themselves): *bad_out (device int32, cleared here) receives the number of rows of the CSR view rowptr[0 .. n_rows] whose
+ * offsets are not 0 <= rowptr[i] <= rowptr[i+1] <= nnz plus the number of entries of that view whose column id minus
+ * col_offset lies outside [0, n_cols) -- i.e. 0 exactly when lkg_spmm_csr_f32 over (rowptr, col, val[nnz], x[n_cols rows]
+ * handed over with that row offset) stays inside its operands.  literalkg_amd.ops.spmm_raw runs it before every launch
+ * when LKG_CHECK_STRUCTURES=1 (the GPU test tier sets it).                                                          */
+int lkg_csr_check_i32(int64_t n_rows, const int32_t *rowptr, int64_t nnz, const int32_t *col, int64_t col_offset,
+                      int64_t n_cols, int32_t *bad_out, void *stream);
 
 /* K8  TransE-form triple scoring (model_bce.py:329-368; same math baselines.py:33-61)
  *   pos_b = |e_h + r - e_p|^2, neg_b = |e_h + r - e_n|^2,

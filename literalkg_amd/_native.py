@@ -32,7 +32,8 @@ PROTOTYPES = {
     "lkg_spmm_csr_scatter_bwd_f32": [i64, i32, vp, vp, vp, vp, i64, vp, i64, vp],
     "lkg_edge_softmax_f32": [i64, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, vp, vp,
                              i32, i32, i32, vp],
-    "lkg_permute_f32": [i64, vp, vp, vp, vp],
+    "lkg_permute_f32": [i64, vp, i64, vp, vp, vp],
+    "lkg_csr_check_i32": [i64, vp, i64, vp, i64, i64, vp, vp],
     "lkg_transe_score_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lkg_loss_reduce_f32": [i64, vp, vp, f32, vp, vp],
     "lkg_transe_score_bwd_f32": [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i64, vp, i64, vp],

@@ -595,15 +595,15 @@ int launch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const 
     return LKG_OK;
 }
 
-inline int spmm_u() {
-    const char *e = getenv("LKG_SPMM_U");
-    return e ? atoi(e) : 4;
-}
-
-inline int grouped_max_chunks() {        // (read per call: the micro-benchmark switches it inside one process)
-    const char *e = getenv("LKG_SPMM_GROUPED_CHUNKS");
-    return e ? atoi(e) : 8;
-}
+// Experiment switches, COMPILE-TIME only (LKG_EXTRA_HIPCC_FLAGS="-DLKG_SPMM_U=8" / "-DLKG_SPMM_GROUPED_CHUNKS=32" and a
+// rebuild): the shipped library holds the measured defaults and nothing in its environment can select a variant that the
+// parity suite never ran (round 3 measured all of them within noise of the defaults at the 5 M / 100 M shape).
+#ifndef LKG_SPMM_U
+#define LKG_SPMM_U 4                     /* gathers in flight per half-wave for 128-column rows: 2 | 4 | 8 */
+#endif
+#ifndef LKG_SPMM_GROUPED_CHUNKS
+#define LKG_SPMM_GROUPED_CHUNKS 8        /* widest row (in 16-byte chunks) that takes several rows per wave: 8 | 16 | 32 */
+#endif
 
 template <typename V>
 int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, const float *val, const float *x,
@@ -623,19 +623,20 @@ int dispatch(int64_t n_rows, int nchunk, const int *rowptr, const int *col, cons
                              : launch_grouped<V, 8, 8, false>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self,
                                                              ld_self, long_rows, n_long, long_thresh, ex, s);
     if constexpr (std::is_same<V, float4>::value) {
-        // experiment (LKG_SPMM_GROUPED_CHUNKS=16|32): several rows per wave for 64- / 128-column rows too
-        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 16 && grouped_max_chunks() >= 16)
+#if LKG_SPMM_GROUPED_CHUNKS >= 16            // (experiment build: several rows per wave for 64- / 128-column rows too)
+        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 16)
             return launch_grouped<V, 16, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
                                                   n_long, long_thresh, ex, s);
-        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 32 && grouped_max_chunks() >= 32)
+#endif
+#if LKG_SPMM_GROUPED_CHUNKS >= 32
+        if (!ex.x_rows && !ex.row_list && n_slabs == 1 && nchunk == 32)
             return launch_grouped<V, 32, 8, true>(n_rows, nchunk, rowptr, col, val, x, ldx, out, ldo, self, ld_self, long_rows,
                                                   n_long, long_thresh, ex, s);
+#endif
     }
     if (nchunk <= 16) LKG_GO(16, 1, 4);
     if (nchunk <= 32) {
-        if (spmm_u() == 8) LKG_GO(32, 1, 8);      // (experiment LKG_SPMM_U=8 | 2: gathers in flight per half-wave)
-        if (spmm_u() == 2) LKG_GO(32, 1, 2);
-        LKG_GO(32, 1, 4);
+        LKG_GO(32, 1, LKG_SPMM_U);
     }
     if (nchunk <= 64) LKG_GO(64, 1, 4);
     if (nchunk <= 128) LKG_GO(64, 2, 4);
@@ -758,7 +759,7 @@ extern "C" int lkg_spmm_csr_fused_f32(int64_t n_rows, int32_t d, const int32_t *
     }
     // (over a row-sparse x almost nothing is gathered: one pass over the entry stream per 256 columns, not per 128)
     const int block_cols = (vec && !x_rows) ? 128 : 256;
-    const bool grouped_slabs = vec && !x_rows && block_cols / 4 <= grouped_max_chunks();   // (experiment: one launch per slab)
+    const bool grouped_slabs = vec && !x_rows && block_cols / 4 <= LKG_SPMM_GROUPED_CHUNKS;   // (experiment: one launch per slab)
     if (d > block_cols && d % block_cols == 0 && !grouped_slabs)     // equal slabs: one launch, slab-major workgroup order
         return vec ? dispatch<float4>(n_rows, block_cols / 4, rowptr, col, val, x, ldx, out, ldo, self, ld_self,
                                       long_rows, n_long, long_thresh, d / block_cols, block_cols, ex, s)
@@ -788,22 +789,69 @@ extern "C" int lkg_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *rowptr
                                   nullptr, 0, nullptr, 0, stream);
 }
 
-// dst[i] = src[perm[i]]
-__global__ void permute_kernel(long n, const int *__restrict__ perm, const float *__restrict__ src,
+// dst[i] = src[perm[i]].  An index outside [0, n_src) is never dereferenced (NaN is stored for it): a list that does not
+// belong to `src` -- round 3's fault: a part's index list paired with the whole value array's length -- shows up as NaNs
+// in the result instead of as a memory access fault of the device.
+__global__ void permute_kernel(long n, long n_src, const int *__restrict__ perm, const float *__restrict__ src,
                                float *__restrict__ dst) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = src[perm[i]];
+    for (; i < n; i += stride) {
+        const long p = perm[i];
+        dst[i] = (p >= 0 && p < n_src) ? src[p] : __builtin_nanf("");
+    }
 }
 
-extern "C" int lkg_permute_f32(int64_t n, const int32_t *perm, const float *src, float *dst, void *stream) {
-    LKG_REQUIRE(n >= 0, "lkg_permute_f32: negative n");
+extern "C" int lkg_permute_f32(int64_t n, const int32_t *perm, int64_t n_src, const float *src, float *dst, void *stream) {
+    LKG_REQUIRE(n >= 0 && n_src >= 0, "lkg_permute_f32: negative extent");
     if (n == 0) return LKG_OK;
     LKG_REQUIRE(perm && src && dst, "lkg_permute_f32: null pointer");
     const int64_t blocks = std::min<int64_t>((n + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, perm, src,
-                       dst);
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, (long)n_src, perm,
+                       src, dst);
     LKG_CHECK_LAUNCH("lkg_permute_f32");
+    return LKG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Structure check: how many offsets / column ids of a CSR (a view into one: rowptr may start anywhere) would make an
+// SpMM over it read outside its operands?  Counts rows whose offsets are not 0 <= rowptr[i] <= rowptr[i + 1] <= nnz and
+// entries of the rows' range whose column id (minus col_offset) lies outside [0, n_cols).  One streaming pass.
+__global__ __launch_bounds__(256) void csr_check_kernel(long n_rows, const int *__restrict__ rowptr, long nnz,
+                                                        const int *__restrict__ col, long col_offset, long n_cols,
+                                                        int *__restrict__ bad) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int mine = 0;
+    for (long i = t0; i < n_rows; i += stride) {
+        const long a = rowptr[i], b = rowptr[i + 1];
+        mine += (a < 0 || a > b || b > nnz) ? 1 : 0;
+    }
+    // the entry range of the view, clamped to the arrays (a bad offset was counted above)
+    long lo = rowptr[0], hi = rowptr[n_rows];
+    lo = lo < 0 ? 0 : (lo > nnz ? nnz : lo);
+    hi = hi < lo ? lo : (hi > nnz ? nnz : hi);
+    for (long j = lo + t0; j < hi; j += stride) {
+        const long c = (long)col[j] - col_offset;
+        mine += (c < 0 || c >= n_cols) ? 1 : 0;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+extern "C" int lkg_csr_check_i32(int64_t n_rows, const int32_t *rowptr, int64_t nnz, const int32_t *col,
+                                 int64_t col_offset, int64_t n_cols, int32_t *bad_out, void *stream) {
+    LKG_REQUIRE(n_rows >= 0 && nnz >= 0 && n_cols >= 0, "lkg_csr_check_i32: negative extent");
+    LKG_REQUIRE(rowptr && bad_out && (col || nnz == 0), "lkg_csr_check_i32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bad_out, 0, sizeof(int32_t), s) != hipSuccess) {
+        lkg_set_error("lkg_csr_check_i32: hipMemsetAsync failed");
+        return LKG_ERR_HIP;
+    }
+    const int64_t work = std::max<int64_t>(n_rows, nnz);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((work + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(csr_check_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (long)n_rows, rowptr, (long)nnz, col,
+                       (long)col_offset, (long)n_cols, bad_out);
+    LKG_CHECK_LAUNCH("lkg_csr_check_i32");
     return LKG_OK;
 }
 

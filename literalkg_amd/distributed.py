@@ -59,6 +59,7 @@ from torch.autograd import Function
 
 from .graph import KGStructure
 from .sharding import FeatureShardedAggregation
+from .transport import InFlight, Pending, Transport
 
 TRAFFIC: collections.Counter = collections.Counter()      # bytes sent by this rank, by kind of exchange
 
@@ -147,8 +148,9 @@ class HipKernels:
         tails, pos = torch.unique(out_col[:m].long(), return_inverse=True)
         gc = ops.gather_rows_range(grad, rows - row0, 0, grad.shape[0])
         buf = torch.zeros((tails.numel(), d), dtype=torch.float32, device=grad.device)
+        pos32 = pos.int()                                          # (a local: it outlives the launch that reads it)
         if m:
-            N.call("lkg_spmm_csr_scatter_bwd_f32", rows.numel(), d, N.ptr(out_rowptr), N.ptr(pos.int()), N.ptr(out_val),
+            N.call("lkg_spmm_csr_scatter_bwd_f32", rows.numel(), d, N.ptr(out_rowptr), N.ptr(pos32), N.ptr(out_val),
                    N.ptr(gc), ops._ld(gc), N.ptr(buf), ops._ld(buf), ops._stream())
         return tails, buf
 
@@ -225,84 +227,36 @@ class RowPartition:
 
 
 # ----------------------------------------------------------------------------------------------- collectives
-def _staged(t: torch.Tensor, group) -> bool:
-    """gloo moves host memory only: device tensors are staged through the host (1-GPU rehearsal of the N > 1 path)."""
-    return t.is_cuda and dist.get_backend(group) == "gloo"
-
-
-class _Pending:
-    """A collective in flight: ``wait()`` returns its result (for a device tensor under RCCL the wait is a stream
-    dependency, the host does not block)."""
-
-    def __init__(self, work, out, after=None):
-        self.work, self.out, self.after = work, out, after
-
-    def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
-        if self.after is not None:
-            self.after()
-            self.after = None
-        return self.out
+# Every exchange goes through ``transport.Transport`` (which alone knows whether RCCL or gloo moves the bytes); the helpers
+# below only add the per-kind traffic count.
+def _counted(tp: Transport, kind: str, pend: Pending, before: int) -> Pending:
+    _sent(kind, tp.bytes_sent - before)
+    return pend
 
 
 def _all_gather(x: torch.Tensor, world: int, group, kind: str = "all_gather", async_op: bool = False):
-    """[R, ...] blocks -> [world * R, ...]; async_op: returns a _Pending issued now (the caller waits where it needs it)."""
-    x = x.contiguous()
-    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    _sent(kind, (world - 1) * x.numel() * x.element_size())
-    if _staged(x, group):
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, x.cpu(), group=group)
-        out.copy_(host)
-        pend = _Pending(None, out)
-    else:
-        pend = _Pending(dist.all_gather_into_tensor(out, x, group=group, async_op=True), out)
+    """[R, ...] blocks -> [world * R, ...]; async_op: returns a Pending issued now (the caller waits where it needs it)."""
+    tp = Transport(group)
+    pend = _counted(tp, kind, tp.all_gather(x), 0)
     return pend if async_op else pend.wait()
 
 
 def _reduce_scatter(x: torch.Tensor, world: int, group, kind: str = "reduce_scatter") -> torch.Tensor:
     """x: [world * R, ...] partial sums -> this rank's [R, ...] block of the sum."""
-    out = torch.empty((x.shape[0] // world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    _sent(kind, (world - 1) * out.numel() * x.element_size())
-    if dist.get_backend(group) == "gloo":      # no reduce_scatter in gloo: all-reduce and slice
-        buf = x.cpu() if x.is_cuda else x.clone()
-        dist.all_reduce(buf, group=group)
-        r = dist.get_rank(group)
-        out.copy_(buf[r * out.shape[0]:(r + 1) * out.shape[0]])
-    else:
-        dist.reduce_scatter_tensor(out, x.contiguous(), group=group)
-    return out
+    tp = Transport(group)
+    return _counted(tp, kind, tp.reduce_scatter(x), 0).wait()
 
 
 def _all_to_all_rows(rows: torch.Tensor, send_counts: List[int], recv_counts: List[int], group, kind: str) -> torch.Tensor:
     """rows [sum(send_counts), ...] sorted by destination -> [sum(recv_counts), ...] sorted by source."""
-    rank = dist.get_rank(group)
+    tp = Transport(group)
     out = torch.empty((sum(recv_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-    per_row = (rows.numel() // max(rows.shape[0], 1)) * rows.element_size() if rows.shape[0] else 0
-    _sent(kind, (sum(send_counts) - send_counts[rank]) * per_row)
-    if _staged(rows, group):
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(host, rows.cpu().contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                               group=group)
-        out.copy_(host)
-    else:
-        dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                               group=group)
-    return out
+    return _counted(tp, kind, tp.all_to_all(out, rows, recv_counts, send_counts), 0).wait()
 
 
 def _all_reduce(x: torch.Tensor, group, kind: str = "all_reduce") -> torch.Tensor:
-    world = dist.get_world_size(group)
-    _sent(kind, 2 * (world - 1) * x.numel() * x.element_size() // max(world, 1))
-    if _staged(x, group):
-        host = x.cpu()
-        dist.all_reduce(host, group=group)
-        x.copy_(host)
-    else:
-        dist.all_reduce(x, group=group)
-    return x
+    tp = Transport(group)
+    return _counted(tp, kind, tp.all_reduce(x), 0).wait()
 
 
 # ----------------------------------------------------------------------------------------------- aggregation
@@ -313,7 +267,7 @@ class DistributedAttention:
     set), "always" (whenever it carries one: small test graphs), "never"."""
 
     def __init__(self, scheme: str, graph: KGStructure, val: torch.Tensor, part: RowPartition, kernels, group=None,
-                 sparse_backward: str = "auto"):
+                 sparse_backward: str = "auto", pipelined: bool = True):
         if scheme not in ("rows", "features"):
             raise ValueError(scheme)
         if sparse_backward not in ("auto", "always", "never"):
@@ -322,6 +276,7 @@ class DistributedAttention:
             raise ValueError(f"the structure has {graph.n} rows, the padded row space {part.n_pad}")
         self.scheme, self.graph, self.part, self.kernels, self.group = scheme, graph, part, kernels, group
         self.sparse_backward = sparse_backward
+        self.pipelined = bool(pipelined)
         self.fs = None
         if scheme == "features":       # (its width argument only sizes the plain slab methods, which are not used here)
             self.fs = FeatureShardedAggregation(graph, val, part.rank, part.world, part.world,
@@ -341,6 +296,27 @@ class DistributedAttention:
 
     def aggregate(self, ego: torch.Tensor, plus_self: bool = False) -> torch.Tensor:
         return _Aggregate.apply(ego, self, plus_self)
+
+    def features_pass(self, transposed: bool, panels: torch.Tensor, plus_self: bool) -> torch.Tensor:
+        """side (transposed: A^T g) of scheme "features" as the row block [G, block, dg] of this rank's rows.
+        pipelined (default): both exchanges folded into the SpMM (FeatureShardedAggregation.exchange_aggregate).
+        pipelined = False: the same result from three plain steps -- ONE all-to-all (row block -> column slab), ONE
+        whole-structure SpMM, ONE all-to-all back: no side stream, no point-to-point group.  It exists so that a first run on
+        real links has a form to bisect against (and a fallback that uses nothing but ``all_to_all_single``)."""
+        fs = self.fs
+        if self.pipelined:
+            return fs.exchange_aggregate(transposed, block_in=panels, plus_self=plus_self)[1]
+        G, rows, dg = panels.shape
+        g = self.graph
+        slab = torch.empty((g.n, dg), dtype=panels.dtype, device=panels.device)
+        counts = [rows] * G
+        fs.tp.all_to_all(slab, panels.view(G * rows, dg), counts, counts).wait()
+        rp, col, val = (g.t_rowptr, g.t_col, fs.val_t) if transposed else (g.rowptr, g.col, fs.val)
+        side = self.kernels.spmm(rp, col, val, slab, g.n, long_rows=g.long_rows(transposed),
+                                 add_self=slab if plus_self else None)
+        out = torch.empty_like(panels)
+        fs.tp.all_to_all(out.view(G * rows, dg), side, counts, counts).wait()
+        return out
 
     # ---- layout helpers of the features scheme: my rows [rows, D] <-> G column panels [G, block, dg]
     def slab_width(self, d: int) -> int:
@@ -383,14 +359,15 @@ class _Aggregate(Function):
         ctx.att, ctx.plus_self = att, plus_self
         ego = ego.contiguous()
         if att.scheme == "rows":
-            pend = _all_gather(p.pad(ego), p.world, att.group, "aggregate_forward", async_op=True)   # issued now ...
-            long_rows = g.long_rows(False, p.pad_lo, p.pad_lo + p.rows)
-            table = pend.wait()                                                                      # ... needed here
-            return k.spmm(g.rowptr[p.pad_lo:p.pad_lo + p.rows + 1], g.col, att.val, table, p.rows, long_rows=long_rows,
-                          add_self=ego if plus_self else None)
+            with InFlight(ego.device) as fl:       # (an exception below leaves with the gather waited for)
+                pend = fl.add(_all_gather(p.pad(ego), p.world, att.group, "aggregate_forward", async_op=True))   # issued now ...
+                long_rows = g.long_rows(False, p.pad_lo, p.pad_lo + p.rows)
+                table = pend.wait()                                                                  # ... needed here
+                return k.spmm(g.rowptr[p.pad_lo:p.pad_lo + p.rows + 1], g.col, att.val, table, p.rows, long_rows=long_rows,
+                              add_self=ego if plus_self else None)
         fs = att.fs
         before = fs.bytes_sent
-        _, out = fs.exchange_aggregate(False, block_in=att.to_panels(ego), plus_self=plus_self)
+        out = att.features_pass(False, att.to_panels(ego), plus_self)
         _sent("aggregate_forward", fs.bytes_sent - before)
         return att.from_panels(out, ego.shape[1])
 
@@ -411,7 +388,7 @@ class _Aggregate(Function):
             edges = torch.tensor([g * p.block for g in range(p.world + 1)], dtype=torch.int64, device=tails.device)
             at = torch.searchsorted(tails, edges)
             counts = torch.cat([(at[1:] - at[:-1]).cpu(), torch.tensor([rows.numel()])])
-        cdev = dev if dist.get_backend(att.group) != "gloo" else torch.device("cpu")
+        cdev = Transport(att.group).control_device(dev)
         every = _all_gather(counts.to(cdev), p.world, att.group, "frontier_counts").view(p.world, p.world + 1).cpu()
         # (frontier rows + flagged rows over all ranks against the table the dense exchange would move: N_pad rows per rank)
         small = att.sparse_backward == "always" or int(every[:, :p.world].sum() + every[:, p.world].sum()) <= p.n_pad // 2
@@ -440,7 +417,7 @@ class _Aggregate(Function):
             return mine, None, None
         fs = att.fs
         before = fs.bytes_sent
-        _, out = fs.exchange_aggregate(True, block_in=att.to_panels(grad), plus_self=ctx.plus_self)
+        out = att.features_pass(True, att.to_panels(grad), ctx.plus_self)
         _sent("aggregate_backward", fs.bytes_sent - before)
         return att.from_panels(out, d), None, None
 
@@ -486,11 +463,13 @@ class ShardedLiteralKG(nn.Module):
     ``model.parameters()`` = this rank's rows of ``entity_embed`` + the replicated weights, so any optimizer keeps the
     entity table's state sharded (no optimizer traffic).  ``full_state_dict()`` gathers a reference-shaped checkpoint."""
 
-    def __init__(self, local, part: RowPartition, scheme: str, kernels, group=None, sparse_backward: str = "auto"):
+    def __init__(self, local, part: RowPartition, scheme: str, kernels, group=None, sparse_backward: str = "auto",
+                 pipelined: bool = True):
         super().__init__()
         self.local = local                   # a LiteralKG over this rank's rows
         self.part, self.scheme, self.kernels, self.group = part, scheme, kernels, group
         self.sparse_backward = sparse_backward
+        self.pipelined = bool(pipelined)     # False: plain all-to-all exchanges around one SpMM (DistributedAttention.features_pass)
         self.n_entities = part.n
         self._att: Optional[DistributedAttention] = None
         local._attention = self._attention   # the layers aggregate through the distributed exchange
@@ -506,7 +485,8 @@ class ShardedLiteralKG(nn.Module):
     def from_full(cls, args, n_entities: int, n_relations: int, state: Dict[str, torch.Tensor], numerical_literals=None,
                   text_literals=None, scoring: str = "transr", scheme: str = "features", device=None, group=None,
                   kernels=None, rank: Optional[int] = None, world: Optional[int] = None,
-                  partition: Optional[str] = None, sparse_backward: str = "auto") -> "ShardedLiteralKG":
+                  partition: Optional[str] = None, sparse_backward: str = "auto",
+                  pipelined: bool = True) -> "ShardedLiteralKG":
         """partition: "rows" (equal row blocks), "entries" (blocks balanced by the stored entries of ``A_in``: the SpMM work of
         scheme "rows") or an explicit list of cut points; default: "entries" for scheme "rows" when the state holds an A_in,
         else "rows".  A rank may own no row at all (more ranks than rows, a cut that leaves a range empty)."""
@@ -544,7 +524,7 @@ class ShardedLiteralKG(nn.Module):
         if [k for k in missing.missing_keys if k != "A_in"] or missing.unexpected_keys:
             raise KeyError(f"state_dict does not match the model: {missing}")
         local.to(device)
-        model = cls(local, part, scheme, kernels, group, sparse_backward)
+        model = cls(local, part, scheme, kernels, group, sparse_backward, pipelined)
         if has_a:
             model.set_attention(a_in.coalesce(), device)
         return model
@@ -565,7 +545,7 @@ class ShardedLiteralKG(nn.Module):
             vals = vals[keep]
         g = self._structure(idx[0], idx[1], None, device)
         self._att = DistributedAttention(self.scheme, g, vals.contiguous(), self.part, self.kernels, self.group,
-                                         self.sparse_backward)
+                                         self.sparse_backward, self.pipelined)
 
     def _attention(self) -> DistributedAttention:
         if self._att is None:
@@ -596,6 +576,14 @@ class ShardedLiteralKG(nn.Module):
         elif hasattr(self.kernels, "checked_ids"):               # every triple's relation id is used as it is: checked
             r = self.kernels.checked_ids(m.n_relations, r, "relation")
         p = self.part
+        # entity ids against the GLOBAL id space, before they are moved into padded coordinates: the padded structure has
+        # n_pad >= n rows, so an id in [n, n_pad) would otherwise be taken for one of another rank's padding rows (the single
+        # module raises for it inside KGStructure.from_triples(n_entities, ...), model.py:446-449 of the reference indexes with it)
+        for name, ids in (("head", h), ("tail", t)):
+            if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= p.n):
+                from ._native import LkgError
+                raise LkgError(f"update_att: {name} id outside [0, {p.n}) (the structure build of the single module "
+                               "refuses the same triple)")
         g = self._structure(h, t, r, dev)
         table = self.entity_table(padded=True)
         rel = m.relation_embed.weight.detach()
@@ -603,7 +591,8 @@ class ShardedLiteralKG(nn.Module):
             val = self.kernels.edge_softmax(g, table, rel, p.pad_lo, p.pad_lo + p.rows)
         else:
             val = self.kernels.edge_softmax(g, table, rel)
-        self._att = DistributedAttention(self.scheme, g, val, p, self.kernels, self.group, self.sparse_backward)
+        self._att = DistributedAttention(self.scheme, g, val, p, self.kernels, self.group, self.sparse_backward,
+                                         self.pipelined)
         m._eval_cache = None
 
     def batch_rows(self, ids: torch.Tensor) -> torch.Tensor:
@@ -673,7 +662,7 @@ class ShardedLiteralKG(nn.Module):
         if self.scheme == "features":
             return torch.sparse_coo_tensor(idx, att.val, (n, n), is_coalesced=True)
         # rows scheme: gather (indices, values) of every rank's rows; row ranges are disjoint and ascending
-        cdev = idx.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
+        cdev = Transport(self.group).control_device(idx.device)
         cnt = torch.tensor([idx.shape[1]], dtype=torch.int64, device=cdev)
         counts = _all_gather(cnt, p.world, self.group, "checkpoint").tolist()
         cap = max(counts)

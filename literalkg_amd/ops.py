@@ -141,6 +141,31 @@ def count_ids_outside(n_rows: int, ids: torch.Tensor) -> int:
 
 
 # ----------------------------------------------------------------------------- raw launches
+import os as _os
+
+CHECK_STRUCTURES = _os.environ.get("LKG_CHECK_STRUCTURES", "0") not in ("", "0")     # validate every raw SpMM's structure first
+
+
+def check_csr(rowptr: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, col_offset: int = 0,
+              what: str = "structure") -> None:
+    """Raise unless an SpMM over the CSR view ``rowptr[0 .. n_rows]`` / ``col`` stays inside ``col`` (and ``val`` of the same
+    length) and inside a source table of ``n_cols`` rows handed over with row offset ``col_offset``: offsets ascending and
+    within [0, col.numel()], column ids within the table (one streaming device pass + one host read: a hardening aid, run
+    where a structure is built or -- LKG_CHECK_STRUCTURES=1 -- before every raw launch)."""
+    _need_gpu(rowptr, col)
+    if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or not rowptr.is_contiguous() or not col.is_contiguous():
+        raise TypeError(f"{what}: rowptr and col must be contiguous int32 tensors")
+    if rowptr.numel() < n_rows + 1:
+        raise ValueError(f"{what}: {rowptr.numel()} offsets for {n_rows} rows")
+    bad = torch.empty(1, dtype=torch.int32, device=col.device)
+    N.call("lkg_csr_check_i32", int(n_rows), N.ptr(rowptr), col.numel(), N.ptr(col), int(col_offset), int(n_cols),
+           N.ptr(bad), _stream())
+    n_bad = int(bad.item())
+    if n_bad:
+        raise N.LkgError(f"{what}: {n_bad} offset(s) / column id(s) would make the SpMM read outside its operands "
+                         f"({n_rows} rows, {col.numel()} stored entries, a source table of {n_cols} rows at offset {col_offset})")
+
+
 def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = None,
              x_row_offset: int = 0, long_rows: Optional[torch.Tensor] = None,
              add_self: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
@@ -168,6 +193,10 @@ def spmm_raw(rowptr, col, val, x, n_rows: int, out: Optional[torch.Tensor] = Non
         raise ValueError(f"spmm_raw: out must be a float32 {n_rows} x {d} tensor with unit column stride (got {tuple(out.shape)})")
     if rowptr.numel() < n_rows + 1 or col.numel() != val.numel():
         raise ValueError("spmm_raw: rowptr needs n_rows + 1 offsets, col and val one element per stored entry")
+    if rowptr.dtype != torch.int32 or col.dtype != torch.int32 or val.dtype != torch.float32:
+        raise TypeError("spmm_raw: int32 offsets and column ids, float32 values")
+    if CHECK_STRUCTURES:
+        check_csr(rowptr, col, n_rows, x.shape[0], x_row_offset, what="spmm_raw")
     if bias is not None:
         if add2 is not None or bias.numel() != d or bias.dtype != torch.float32 or not bias.is_contiguous():
             raise ValueError(f"spmm_raw: bias must be a contiguous float32 vector of {d} elements and excludes add2")
@@ -661,7 +690,7 @@ def permute_values(val: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     if perm.dtype != torch.int32 or val.dtype != torch.float32 or not perm.is_contiguous() or not val.is_contiguous():
         raise TypeError("permute_values: contiguous float32 values and a contiguous int32 index list")
     out = torch.empty(perm.numel(), dtype=val.dtype, device=val.device)
-    N.call("lkg_permute_f32", perm.numel(), N.ptr(perm), N.ptr(val), N.ptr(out), _stream())
+    N.call("lkg_permute_f32", perm.numel(), N.ptr(perm), val.numel(), N.ptr(val), N.ptr(out), _stream())
     return out
 
 

@@ -27,14 +27,13 @@ Backward : grad_ego = A^T grad_side.  The slice's transpose yields a partial N x
 """
 from __future__ import annotations
 
-import contextlib
 from typing import Callable, List, Optional
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .graph import KGStructure
+from .transport import InFlight, Transport
 
 
 class ShardedAggregation:
@@ -51,6 +50,7 @@ class ShardedAggregation:
         self.val = val
         self.val_t = permute(val, graph.t_perm)
         self.group = group
+        self.tp = Transport(group)
         n = graph.n
         self.chunks = [(int(a), int(b)) for a, b in zip(np.linspace(0, n, n_chunks + 1)[:-1].astype(np.int64),
                                                          np.linspace(0, n, n_chunks + 1)[1:].astype(np.int64)) if b > a]
@@ -69,15 +69,13 @@ class ShardedAggregation:
         d = grad_rows.shape[1]
         if out is None:
             out = torch.empty((g.n, d), dtype=grad_rows.dtype, device=grad_rows.device)
-        works = []
-        multi = reduce and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        for a, b in self.chunks:
-            self.spmm(g.t_rowptr[a:b + 1], g.t_col, self.val_t, grad_rows, b - a, out=out[a:b],
-                      x_row_offset=self.lo, long_rows=g.long_rows(True, a, b))
-            if multi:
-                works.append(dist.all_reduce(out[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+        multi = reduce and self.tp.multi
+        with InFlight(out.device) as fl:       # (leaves -- also by exception -- with every reduction waited for)
+            for a, b in self.chunks:
+                self.spmm(g.t_rowptr[a:b + 1], g.t_col, self.val_t, grad_rows, b - a, out=out[a:b],
+                          x_row_offset=self.lo, long_rows=g.long_rows(True, a, b))
+                if multi:
+                    fl.add(self.tp.all_reduce(out[a:b]))
         return out
 
 
@@ -137,9 +135,14 @@ class FeatureShardedAggregation:
         self.rows = [self.cuts[i + 1] - self.cuts[i] for i in range(world)]
         self.my_rows = self.rows[rank]
         self.group = group
+        self.tp = Transport(group)    # every byte that leaves this rank goes through it (and is counted there)
         self._parts = {}              # (transposed, batches) -> (StructureParts, their values)
-        self.bytes_sent = 0           # payload bytes this rank handed to the collective library (tests count them)
         self.set_values(val)
+
+    @property
+    def bytes_sent(self) -> int:
+        """payload bytes this rank handed to the collective library (tests count them)"""
+        return self.tp.bytes_sent
 
     @staticmethod
     def slab_width(d: int, world: int) -> int:
@@ -210,10 +213,6 @@ class FeatureShardedAggregation:
         return self.spmm(g.t_rowptr, g.t_col, self.val_t, grad_slab, g.n, out=out, long_rows=g.long_rows(True))
 
     # ------------------------------------------------------------------ SpMM pipelined with its exchanges
-    def _staged(self, t: torch.Tensor) -> bool:
-        """gloo moves host memory only: device tensors are staged through the host (1-GPU rehearsal of the N > 1 path)"""
-        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
-
     def exchange_aggregate(self, transposed: bool, slab: Optional[torch.Tensor] = None,
                            block_in: Optional[torch.Tensor] = None, plus_self: bool = False, exchange_out: bool = True,
                            n_batches: Optional[int] = None, pieces: Optional[int] = None,
@@ -224,73 +223,66 @@ class FeatureShardedAggregation:
                   them);
           output  exchange_out: (side_slab, row block [G, rows_r, D/G]) -- the last part leaves owner range by owner range
                   (each range in ``pieces`` pieces); otherwise side_slab [N, D/G] alone.
-        plus_self: side = x + A x (the layer's ``ego + side``, model.py:109)."""
+        plus_self: side = x + A x (the layer's ``ego + side``, model.py:109).
+        Every transfer and side stream of the pass belongs to one ``InFlight``: the pass returns -- or raises -- with all of
+        them waited for and joined."""
         g, r, G = self.graph, self.rank, self.world
         if (slab is None) == (block_in is None):
             raise ValueError("exchange_aggregate: exactly one of slab / block_in")
         src = slab if slab is not None else block_in
         dev, dtype, dg = src.device, src.dtype, int(src.shape[-1])     # (any width: the structure's parts do not depend on it)
         whole = _Whole(g, transposed)
-        if block_in is not None and G > 1:
-            if tuple(block_in.shape) != (G, self.my_rows, dg) or not block_in.is_contiguous():
-                raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected a contiguous {(G, self.my_rows, dg)}")
-            n_chunks, parts, vals = self.parts(transposed, n_batches)
-            bounds = self.chunk_bounds(n_chunks)
-            slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
-            slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # the own block: no transfer
-            staged = self._staged(block_in)
-            queued = [([], [])]              # (part 0 = the own block waits for nothing)
-            for q in range(n_chunks):        # ALL batches are queued now, in order, on the collective library's stream
-                ops_, host = [], []
-                mlo, mhi = bounds[r][q] - self.cuts[r], bounds[r][q + 1] - self.cuts[r]      # sub-range q of MY rows
-                for k in range(1, G):
-                    j, i = (r + k) % G, (r - k) % G
-                    if mhi > mlo:
-                        piece = block_in[j, mlo:mhi]
-                        ops_.append(dist.P2POp(dist.isend, piece.cpu() if staged else piece, j, self.group))
-                        self.bytes_sent += piece.numel() * block_in.element_size()
-                    if bounds[i][q + 1] > bounds[i][q]:
-                        dst = slab[bounds[i][q]:bounds[i][q + 1]]
-                        rcv = torch.empty(dst.shape, dtype=dtype) if staged else dst
-                        if staged:
-                            host.append((rcv, dst))
-                        ops_.append(dist.P2POp(dist.irecv, rcv, i, self.group))
-                queued.append((dist.batch_isend_irecv(ops_) if ops_ else [], host))
-            assert len(queued) == len(parts)
-        else:
-            if block_in is not None:         # one rank: the row block IS the slab
-                slab = block_in[0]
-            parts = [whole]
-            vals = [self.val_t if transposed else self.val]
-            queued = [([], [])]
-        if side_slab is None:
-            side_slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
-        live = [b for b, p in enumerate(parts) if p.nnz > 0] or [0]
-        first = True
-
-        def arrived(b):
-            works, host = queued[b]
-            for w in works:
-                w.wait()
-            for rcv, dst in host:
-                dst.copy_(rcv)
-            queued[b] = ([], [])
-
-        for b in range(len(parts)):
-            arrived(b)
-            if b not in live:
-                continue
-            part, val_p = parts[b], vals[b]
-            if b == live[-1]:                # the last pass: x itself is added here (plus_self), when ALL of it has arrived
-                for later in range(b + 1, len(parts)):
-                    arrived(later)
-            add_self = slab if (plus_self and b == live[-1]) else None
-            if b == live[-1] and exchange_out and G > 1:
-                out = self._ranges_to_row_block(part, val_p, slab, side_slab, first, add_self, out, pieces)
+        if block_in is not None and G > 1 and (tuple(block_in.shape) != (G, self.my_rows, dg) or not block_in.is_contiguous()):
+            raise ValueError(f"row block of shape {tuple(block_in.shape)}, expected a contiguous {(G, self.my_rows, dg)}")
+        with InFlight(dev) as fl:
+            if block_in is not None and G > 1:
+                n_chunks, parts, vals = self.parts(transposed, n_batches)
+                bounds = self.chunk_bounds(n_chunks)
+                slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
+                slab[self.cuts[r]:self.cuts[r + 1]].copy_(block_in[r])               # the own block: no transfer
+                queued = [None]                  # (part 0 = the own block waits for nothing)
+                for q in range(n_chunks):        # ALL batches are queued now, in order, on the collective library's stream
+                    sends, recvs = [], []
+                    mlo, mhi = bounds[r][q] - self.cuts[r], bounds[r][q + 1] - self.cuts[r]      # sub-range q of MY rows
+                    for k in range(1, G):
+                        j, i = (r + k) % G, (r - k) % G
+                        if mhi > mlo:
+                            sends.append((block_in[j, mlo:mhi], j))
+                        if bounds[i][q + 1] > bounds[i][q]:
+                            recvs.append((slab[bounds[i][q]:bounds[i][q + 1]], i))
+                    queued.append(fl.add(self.tp.p2p(sends, recvs)))
+                assert len(queued) == len(parts)
             else:
-                self.spmm(part.rowptr, part.col, val_p, slab, g.n, out=side_slab, long_rows=part.long_rows(),
-                          add_self=add_self, add2=None if first else side_slab)
-            first = False
+                if block_in is not None:         # one rank: the row block IS the slab
+                    slab = block_in[0]
+                parts = [whole]
+                vals = [self.val_t if transposed else self.val]
+                queued = [None]
+            if side_slab is None:
+                side_slab = torch.empty((g.n, dg), dtype=dtype, device=dev)
+            live = [b for b, p in enumerate(parts) if p.nnz > 0] or [0]
+            first = True
+
+            def arrived(b):
+                if queued[b] is not None:
+                    queued[b].wait()
+                    queued[b] = None
+
+            for b in range(len(parts)):
+                arrived(b)
+                if b not in live:
+                    continue
+                part, val_p = parts[b], vals[b]
+                if b == live[-1]:                # the last pass: x itself is added here (plus_self), when ALL of it has arrived
+                    for later in range(b + 1, len(parts)):
+                        arrived(later)
+                add_self = slab if (plus_self and b == live[-1]) else None
+                if b == live[-1] and exchange_out and G > 1:
+                    out = self._ranges_to_row_block(fl, part, val_p, slab, side_slab, first, add_self, out, pieces)
+                else:
+                    self.spmm(part.rowptr, part.col, val_p, slab, g.n, out=side_slab, long_rows=part.long_rows(),
+                              add_self=add_self, add2=None if first else side_slab)
+                first = False
         if not exchange_out:
             return side_slab
         if G == 1:
@@ -299,7 +291,7 @@ class FeatureShardedAggregation:
             out[0].copy_(side_slab)
         return side_slab, out
 
-    def _ranges_to_row_block(self, part, val_p, slab, side_slab, first, add_self, out, pieces):
+    def _ranges_to_row_block(self, fl: InFlight, part, val_p, slab, side_slab, first, add_self, out, pieces):
         """The last SpMM pass of ``exchange_aggregate`` fused with the slab -> row block exchange: the pass runs owner
         range by owner range, and as soon as a piece of the rows owned by rank j is done it leaves for rank j
         (point-to-point, the collective library's stream, one xGMI link per peer) while the next piece is being aggregated.
@@ -310,14 +302,14 @@ class FeatureShardedAggregation:
         On the GPU the row-range launches alternate between two side streams: back to back on ONE stream every extra
         launch costs ~25 us of tail and gap (5 M rows x 100 M entries x 32 columns: 1 launch 2.16 ms, 8: 2.30,
         32: 2.94), on two alternating streams the tail of one overlaps the start of the next (32 launches: 2.25 ms)
-        and each piece still completes -- and leaves -- in order."""
+        and each piece still completes -- and leaves -- in order.  The streams and the transfers are ``fl``'s: the caller's
+        ``InFlight`` joins and waits them, on the normal path and on an exception alike."""
         r, G = self.rank, self.world
         if pieces is None:
             pieces = 4
         dg = int(slab.shape[1])
         if out is None:
             out = torch.empty((G, self.my_rows, dg), dtype=slab.dtype, device=slab.device)
-        staged = self._staged(slab)
 
         def piece(lo, hi, p):      # p-th of `pieces` sub-ranges of [lo, hi)
             n = hi - lo
@@ -327,63 +319,45 @@ class FeatureShardedAggregation:
         if slab.is_cuda:
             if not hasattr(self, "_side_streams"):
                 self._side_streams = [torch.cuda.Stream(device=slab.device) for _ in range(2)]
-            streams = self._side_streams
-            main = torch.cuda.current_stream(slab.device)
-            for st in streams:
-                st.wait_stream(main)
-        works, host, step = [], [], 0
+            streams = fl.fork(self._side_streams)
+        step = 0
 
         def launch(lo, hi):
             nonlocal step
-            ctx = torch.cuda.stream(streams[step % len(streams)]) if streams else contextlib.nullcontext()
+            st = streams[step % len(streams)] if streams else None
             step += 1
-            with ctx:
+            with fl.on(st):
                 if hi > lo:
                     self.spmm(part.rowptr[lo:hi + 1], part.col, val_p, slab, hi - lo, out=side_slab[lo:hi],
                               long_rows=part.long_rows(lo, hi), add_self=add_self[lo:hi] if add_self is not None else None,
                               add2=None if first else side_slab[lo:hi])
+            return st
 
         # The OTHER ranks' rows first, in `pieces` rounds: round p computes piece p of every other rank's range and then hands
         # the round's G - 1 sends and receives to the collective library in ONE group (all links busy; 4 groups per pass
         # instead of 28: the host has to stay ahead of 2.3 ms of launches).  This rank's own rows LAST, in one launch: they need
         # no transfer, so the last round (1 / pieces of a block per link) travels behind 1 / G of the pass instead of nothing.
         for p in range(pieces):
-            ops_ = []
+            sends, recvs = [], []
             for k in range(1, G):
                 j, i = (r + k) % G, (r - k) % G
                 lo, hi = piece(self.cuts[j], self.cuts[j + 1], p)
                 launch(lo, hi)
                 rlo, rhi = piece(0, self.my_rows, p)              # the matching piece of MY rows, arriving from rank i
                 if hi > lo:
-                    snd = side_slab[lo:hi]
-                    ops_.append((dist.isend, snd, j))
-                    self.bytes_sent += (hi - lo) * dg * side_slab.element_size()
+                    sends.append((side_slab[lo:hi], j))
                 if rhi > rlo:
-                    if staged:
-                        rcv = torch.empty((rhi - rlo, dg), dtype=out.dtype)
-                        host.append((rcv, i, rlo, rhi))
-                    else:
-                        rcv = out[i, rlo:rhi]
-                    ops_.append((dist.irecv, rcv, i))
-            if not ops_:
+                    recvs.append((out[i, rlo:rhi], i))
+            if not (sends or recvs):
                 continue
             if streams:                       # the round's pieces sit on both compute streams: the group goes behind both
                 streams[0].wait_stream(streams[1])
-            ctx = torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()
-            with ctx:          # the collective library orders its transfers behind the CURRENT stream, i.e. this round
-                works += dist.batch_isend_irecv([dist.P2POp(fn, (t_.cpu() if (staged and fn is dist.isend) else t_), peer, self.group)
-                                                 for fn, t_, peer in ops_])
-        launch(self.cuts[r], self.cuts[r + 1])
-        ctx = torch.cuda.stream(streams[(step - 1) % len(streams)]) if streams else contextlib.nullcontext()
-        with ctx:
+            with fl.on(streams[0] if streams else None):   # the library orders its transfers behind the CURRENT stream: this round
+                fl.add(self.tp.p2p(sends, recvs))
+        last = launch(self.cuts[r], self.cuts[r + 1])
+        with fl.on(last):
             out[r].copy_(side_slab[self.cuts[r]:self.cuts[r + 1]])
-        if streams:
-            for st in streams:
-                main.wait_stream(st)
-        for w in works:
-            w.wait()
-        for rcv, i, rlo, rhi in host:
-            out[i, rlo:rhi].copy_(rcv)
+        fl.join()
         return out
 
     def forward_to_row_block(self, slab: torch.Tensor, side_slab: Optional[torch.Tensor] = None,
@@ -414,25 +388,16 @@ class FeatureShardedAggregation:
         if pieces == 1:
             return self.backward_in_head_parts(block, out=out)
         w = self.dg // pieces
-        staged = self._staged(block)
-        queue = []
-        for p in range(pieces):
-            src = block[:, :, p * w:(p + 1) * w].contiguous().view(self.world * self.my_rows, w)
-            dst = torch.empty((g.n, w), dtype=block.dtype, device=block.device)
-            self.bytes_sent += (self.world - 1) * self.my_rows * w * block.element_size()
-            if staged or not block.is_cuda:
-                self._all_to_all(dst, src, self.rows, [self.my_rows] * self.world, count=False)
-                work = None
-            else:
-                work = dist.all_to_all_single(dst, src, output_split_sizes=self.rows,
-                                              input_split_sizes=[self.my_rows] * self.world, group=self.group,
-                                              async_op=True)
-            queue.append((work, dst, src))
-        for p, (work, dst, _src) in enumerate(queue):
-            if work is not None:
-                work.wait()
-            self.spmm(g.t_rowptr, g.t_col, self.val_t, dst, g.n, out=out[:, p * w:(p + 1) * w],
-                      long_rows=g.long_rows(True))
+        with InFlight(block.device) as fl:
+            queue = []
+            for p in range(pieces):              # every piece's exchange is queued now; piece p's SpMM runs behind piece p + 1's
+                src = block[:, :, p * w:(p + 1) * w].contiguous().view(self.world * self.my_rows, w)
+                dst = torch.empty((g.n, w), dtype=block.dtype, device=block.device)
+                queue.append((fl.add(self.tp.all_to_all(dst, src, self.rows, [self.my_rows] * self.world)), src))
+            for p, (pend, _src) in enumerate(queue):
+                dst = pend.wait()
+                self.spmm(g.t_rowptr, g.t_col, self.val_t, dst, g.n, out=out[:, p * w:(p + 1) * w],
+                          long_rows=g.long_rows(True))
         return out
 
     def backward_in_head_parts(self, block: torch.Tensor, out: Optional[torch.Tensor] = None,
@@ -456,7 +421,7 @@ class FeatureShardedAggregation:
         if self.world == 1:
             out[0].copy_(slab)
             return out
-        self._all_to_all(out.view(self.world * self.my_rows, self.dg), slab, [self.my_rows] * self.world, self.rows)
+        self.tp.all_to_all(out.view(self.world * self.my_rows, self.dg), slab, [self.my_rows] * self.world, self.rows).wait()
         return out
 
     def to_column_slab(self, block: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -466,17 +431,5 @@ class FeatureShardedAggregation:
         if self.world == 1:
             out.copy_(block[0])
             return out
-        self._all_to_all(out, block.view(self.world * self.my_rows, self.dg), self.rows, [self.my_rows] * self.world)
+        self.tp.all_to_all(out, block.view(self.world * self.my_rows, self.dg), self.rows, [self.my_rows] * self.world).wait()
         return out
-
-    def _all_to_all(self, out, inp, out_splits, in_splits, count=True):
-        if count:
-            self.bytes_sent += (sum(in_splits) - in_splits[self.rank]) * inp.shape[1] * inp.element_size()
-        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
-            # gloo moves host memory only (single-GPU rehearsal of the N>1 path): stage through the host
-            host_out = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
-                                   group=self.group)
-            out.copy_(host_out)
-            return
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# every raw SpMM launch of the test tiers validates its structure first (ops.check_csr; read when literalkg_amd.ops is imported)
+os.environ.setdefault("LKG_CHECK_STRUCTURES", "1")
 
 
 def pytest_configure(config):

@@ -64,18 +64,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         sh = ShardedAggregation(mine, val_mine, lo, hi, n_chunks=3)
         ok &= torch.allclose(sh.forward(ent), want_side[lo:hi], rtol=1e-5, atol=1e-5)
 
-        def staged_all_reduce(x, op=None, group=None, async_op=False):      # gloo moves host memory only
-            hx = x.cpu()
-            _orig(hx, op=dist.ReduceOp.SUM, group=group)
-            x.copy_(hx)
-            return type("W", (), {"wait": lambda self: None})()
-        _orig = dist.all_reduce
-        if not nccl:
-            dist.all_reduce = staged_all_reduce
-        try:
-            grad = sh.backward(gside[lo:hi].contiguous())
-        finally:
-            dist.all_reduce = _orig
+        grad = sh.backward(gside[lo:hi].contiguous())      # (the chunked all-reduce goes through transport.Transport)
         ok &= torch.allclose(grad, want_grad, rtol=1e-5, atol=1e-4)
         q.put((rank, bool(ok)))
     finally:
@@ -213,18 +202,7 @@ def _sweep_worker(rank, world, port, seeds, q):
             sh = ShardedAggregation(mine, val_mine, lo, hi, n_chunks=int(pick([1, 2, 3, 5])))
             if hi > lo:
                 torch.testing.assert_close(sh.forward(x), want_side[lo:hi], msg=lambda m_: f"row-range forward {what}: {m_}", **tol)
-            real = dist.all_reduce
-
-            def staged_all_reduce(x_, op=None, group=None, async_op=False):      # gloo moves host memory only
-                hx = x_.cpu()
-                real(hx, op=dist.ReduceOp.SUM, group=group)
-                x_.copy_(hx)
-                return type("W", (), {"wait": lambda self: None})()
-            dist.all_reduce = staged_all_reduce
-            try:
-                grad = sh.backward(gx[lo:hi].contiguous())
-            finally:
-                dist.all_reduce = real
+            grad = sh.backward(gx[lo:hi].contiguous())         # (chunked all-reduce through transport.Transport)
             torch.testing.assert_close(grad, want_grad, msg=lambda m_: f"row-range backward {what}: {m_}", **tol)
             dist.barrier()
             n_done += 1

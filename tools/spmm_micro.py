@@ -17,7 +17,6 @@ ap.add_argument("--e", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--device-graph", action="store_true", help="draw the graph on the device (fast; no de-duplication, no degree clip)")
 ap.add_argument("--only-main", action="store_true", help="time only the library's default forward / transpose launches (PMC passes)")
-ap.add_argument("--grouped", default="", help="comma list of LKG_SPMM_GROUPED_CHUNKS values to time as well (experiment)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ap_skews = ("zipf", "uniform") if args.e <= 20_000_000 else ("zipf",)
@@ -71,22 +70,8 @@ for skew in ap_skews:
         med, mn = timeit(fn)
         print(f"{skew:8s} D={d} {name} median {med:.3f} ms  min {mn:.3f} ms  -> {by/med/1e6:.0f} GB/s algorithmic "
               f"({by/med/1e6/8000:.3f} of 8 TB/s)  long rows: {0 if g.long_rows(False) is None else g.long_rows(False).numel()}")
-    for gval in [v for v in args.grouped.split(",") if v]:
-        os.environ["LKG_SPMM_GROUPED_CHUNKS"] = gval
-        for name, fn in [("fwd", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
-                         ("bwd", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out, long_rows=g.long_rows(True)))]:
-            med, mn = timeit(fn)
-            print(f"{skew:8s} D={d} {name} rows-per-wave kernel for <= {gval} chunks: median {med:.3f} ms  min {mn:.3f} ms -> "
-                  f"{by/med/1e6:.0f} GB/s ({by/med/1e6/8000:.3f} of 8 TB/s)")
-        del os.environ["LKG_SPMM_GROUPED_CHUNKS"]
-    for uval in [v for v in os.environ.get("LKG_MICRO_U", "").split(",") if v]:
-        os.environ["LKG_SPMM_U"] = uval
-        for name, fn in [("fwd", lambda: ops.spmm_raw(g.rowptr, g.col, val, x, args.n, out=out, long_rows=g.long_rows(False))),
-                         ("bwd", lambda: ops.spmm_raw(g.t_rowptr, g.t_col, val_t, x, args.n, out=out, long_rows=g.long_rows(True)))]:
-            med, mn = timeit(fn)
-            print(f"{skew:8s} D={d} {name} U={uval} gathers in flight per half-wave: median {med:.3f} ms  min {mn:.3f} ms -> "
-                  f"{by/med/1e6:.0f} GB/s ({by/med/1e6/8000:.3f} of 8 TB/s)")
-        del os.environ["LKG_SPMM_U"]
+    # (the rows-per-wave / gathers-in-flight experiments are COMPILE-TIME variants since round 4: rebuild with
+    #  LKG_EXTRA_HIPCC_FLAGS="-DLKG_SPMM_GROUPED_CHUNKS=32" or "-DLKG_SPMM_U=8" and run this tool again)
     # plain copy reference for this box: read+write 2 x table
     y = torch.empty_like(x)
     med, _ = timeit(lambda: y.copy_(x))
