@@ -38,7 +38,7 @@
 namespace {
 
 #ifndef LKG_TALL_DEFAULT_VARIANT
-#define LKG_TALL_DEFAULT_VARIANT 2      /* 256x1: measured fastest (1 M x 256 x 256: 0.62 ms against 0.76 / 0.71) */
+#define LKG_TALL_DEFAULT_VARIANT 3      /* 0 "256x2", 1 "128x1", 2 "256x1" (8 waves of 64 x 64), 3 "256x1w" (4 waves of 64 x 128) */
 #endif
 constexpr int TM = 128, TK = 16, MAX_PANELS = 3;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -79,10 +79,14 @@ __device__ __forceinline__ int scale_exponent(float mx) {
     return max(-100, min(100, 13 - (ex - 127)));
 }
 
-// one element group -> hi / mid fp16 pairs
+// one element group -> hi / mid fp16 pairs.  PRE: the residual is stored as it is (mid' = a' - hi, the 2^-11 of the cross
+// terms already inside the operand: fp16 subnormals for elements below 2^-17 of their row maximum) instead of scaled by
+// 2^11 into fp16's normal range -- the one-accumulator kernels of 64 x 128 wave tiles use it and need no scaled copy of hi.
+template <bool PRE = false>
 __device__ __forceinline__ void split2(float a0, float a1, fp16x2 &hi, fp16x2 &mid) {
     hi = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-    const float r0 = (a0 - (float)hi[0]) * 2048.f, r1 = (a1 - (float)hi[1]) * 2048.f;
+    constexpr float sc = PRE ? 1.f : 2048.f;
+    const float r0 = (a0 - (float)hi[0]) * sc, r1 = (a1 - (float)hi[1]) * sc;
     mid = __builtin_amdgcn_cvt_pkrtz(r0, r1);
 }
 
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void b_exponent_kernel(BDesc b, int n_stacked,
 // planes of one (n tile, k tile): thread = tile row
 template <int BN>
 __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total, const int *__restrict__ eb,
-                                                      _Float16 *__restrict__ out) {
+                                                      _Float16 *__restrict__ out, int pre) {
     const int tn = blockIdx.x / ktiles_total, kt = blockIdx.x % ktiles_total;
     int p = 0, k0 = kt;
     while (p < b.n_panels - 1 && k0 >= (b.k[p] + TK - 1) / TK) {
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
         if (ok && k0 + k < b.k[p]) v0 = ldexpf(b_elem(b, group, row, p, k0 + k), e);
         if (ok && k0 + k + 1 < b.k[p]) v1 = ldexpf(b_elem(b, group, row, p, k0 + k + 1), e);
         fp16x2 hi, mid;
-        split2(v0, v1, hi, mid);
+        if (pre) split2<true>(v0, v1, hi, mid); else split2<false>(v0, v1, hi, mid);
         const int off = plane_off(threadIdx.x, k);
         *reinterpret_cast<fp16x2 *>(dst + off) = hi;
         *reinterpret_cast<fp16x2 *>(dst + BN * TK + off) = mid;
@@ -168,10 +172,17 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
 // second accumulator: hs = hi * 2^-11 (an exact exponent shift, one v_pk_mul_f16 per register, down to fp16's
 // subnormals for elements below 2^-17 of their row maximum) and  a'.b' = hi_a hi_b + hs_a mid_b + mid_a hs_b.  64
 // accumulator registers less per lane: three 4-wave workgroups (or two 8-wave ones) share a CU and their phases overlap.
-template <int BN, int EPI, bool ONE>
-__global__ __launch_bounds__(2 * BN) __attribute__((amdgpu_waves_per_eu(ONE ? (BN == 128 ? 3 : 4) : 2, ONE ? (BN == 128 ? 3 : 4) : 2)))
+// WN: columns per wave.  64: 2 x BN/64 waves of 64 x 64 (the forms above).  128 (BN = 256, one accumulator, prescaled
+// mids): FOUR waves of 64 x 128 -- one wave per SIMD and workgroup, two workgroups per CU at up to 256 VGPRs each, 24 MFMAs
+// per wave and barrier instead of 12, 48 KB of fragment reads per step instead of 64 KB, no scaled operand copies: while one
+// workgroup of a CU stores its tile the other has the matrix pipe of all four SIMDs to itself.
+template <int BN, int EPI, bool ONE, int WN = 64>
+__global__ __launch_bounds__(2 * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2), WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2))))
 void gemm_tall_kernel(TallArgs g) {
-    constexpr int NT = 2 * BN;                    // threads
+    static_assert(WN == 64 || (WN == 128 && BN == 256 && ONE), "64 x 128 wave tiles: 256-column tiles, one accumulator");
+    constexpr bool PRE = WN == 128;               // mid planes hold the residual itself (split2<true>)
+    constexpr int NJ = WN / 32;                   // 32-column blocks per wave
+    constexpr int NT = 2 * (BN / WN) * 64;        // threads
     constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
     constexpr int TPR = TK / EPT;                 // threads per A row
     constexpr int APL = TM * TK, BPL = BN * TK;   // halves per plane
@@ -197,7 +208,7 @@ void gemm_tall_kernel(TallArgs g) {
     // compiler cannot hoist out of the persistent loop, where it would occupy registers across a k loop that has none to
     // spare (hoisted, 25-58 VGPRs spilled around it; re-derived, a few dozen integer instructions per 60 k-cycle tile).
     int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int wm = wave / (BN / 64), wn = wave % (BN / 64);
+    int wm = wave / (BN / WN), wn = wave % (BN / WN);
     // PERSISTENT workgroups, XCD-aware: workgroup b lives on XCD b & 7 and walks every (gridDim.x / 8)-th tile of that XCD's
     // contiguous range of row tiles (n fastest).  Before a tile's epilogue the workgroup requests the NEXT tile's first B
     // planes and A windows: the HBM round trip that used to open every tile (7-8 k cycles of 60 k) runs under the epilogue.
@@ -213,14 +224,14 @@ void gemm_tall_kernel(TallArgs g) {
         int t_o = threadIdx.x;
         asm volatile("" : "+v"(t_o));
         t = t_o; lane = t & 63; wave = t >> 6;
-        wm = wave / (BN / 64); wn = wave % (BN / 64);
+        wm = wave / (BN / WN); wn = wave % (BN / WN);
         arow = t / TPR; akc = t % TPR;
     };
     // ---- per-tile state (set by setup(): the tile being computed, or -- from just before its epilogue on -- the next one)
     long m0 = 0, grow = 0;
     int n0 = 0, ea = 0;
 
-    f32x16 acc[2][2], cor[ONE ? 1 : 2][ONE ? 1 : 2];
+    f32x16 acc[2][NJ], cor[ONE ? 1 : 2][ONE ? 1 : 2];
 
     // ONE branch-free load path for every tile of every panel (aligned or not, full or partial): a 16-byte window per
     // thread, its address clamped to the panel's last valid window (rows past m reuse row m-1, never stored; a window
@@ -341,8 +352,10 @@ void gemm_tall_kernel(TallArgs g) {
         typedef __attribute__((address_space(1))) const uint4 gu4;
         const uint4 *src = bsrc + (long)min(tile_k, n_tiles - 1) * (2 * BPL / 8);
         uint4 *d = reinterpret_cast<uint4 *>(D + 2 * APL) + wave * 64;
-        __builtin_amdgcn_global_load_lds((gu4 *)src, (lds_void *)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gu4 *)(src + BPL / 8), (lds_void *)(d + BPL / 8), 16, 0, 0);
+        constexpr int NB = (2 * BPL / 8) / NT;     // 16-byte DMAs per thread for the two planes: 2 (512 threads) or 4 (256)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            __builtin_amdgcn_global_load_lds((gu4 *)(src + q * NT), (lds_void *)(d + q * NT), 16, 0, 0);
     };
     int st_k0 = 0, st_kp = 0;                      // the tile being staged: first k of this thread's windows, panel width
     unsigned st_sh = 0;
@@ -389,8 +402,8 @@ void gemm_tall_kernel(TallArgs g) {
         // fragments are fetched where their registers become free (all eight up front would hold 32 registers at once)
         f16x8 a0[2], b0[2], a1[2], b1[2];
         auto fa = [&](int i, int pl) { return frag<BN>(S + pl * APL, wm * 64 + i * 32, lane); };
-        auto fb = [&](int j, int pl) { return frag<BN>(S + 2 * APL + pl * BPL, wn * 64 + j * 32, lane); };
-        a0[0] = fa(0, 0); b0[0] = fb(0, 0); b0[1] = fb(1, 0); a0[1] = fa(1, 0);
+        auto fb = [&](int j, int pl) { return frag<BN>(S + 2 * APL + pl * BPL, wn * WN + j * 32, lane); };
+        if constexpr (!PRE) { a0[0] = fa(0, 0); b0[0] = fb(0, 0); b0[1] = fb(1, 0); a0[1] = fa(1, 0); }
         const _Float16 sc = (_Float16)(1.f / 2048.f);
         f16x8 ahs[2], bhs[2];
         float e[EPT];
@@ -429,10 +442,11 @@ void gemm_tall_kernel(TallArgs g) {
             }
         };
         auto p_res = [&]() {
+            constexpr float rs = PRE ? 1.f : 2048.f;
 #pragma unroll
             for (int u = 0; u < EPT; u += 2) {
-                e[u] = (e[u] - (float)hi[u / 2][0]) * 2048.f;
-                e[u + 1] = (e[u + 1] - (float)hi[u / 2][1]) * 2048.f;
+                e[u] = (e[u] - (float)hi[u / 2][0]) * rs;
+                e[u + 1] = (e[u + 1] - (float)hi[u / 2][1]) * rs;
             }
         };
         auto p_mid = [&]() {
@@ -452,7 +466,38 @@ void gemm_tall_kernel(TallArgs g) {
         };
 #define LKG_MFMA(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
         LKG_PIN();
-        if constexpr (ONE) {
+        if constexpr (PRE) {
+            // 24 MFMAs: hi.hi, mid'.hi, hi.mid' over the wave's 2 x 4 blocks; a fragment is fetched where its registers
+            // come free (peak: a hi 8 + b hi 16 + a mid' 8 + two b mid' 8), the split of the next tile rides behind them
+            static_assert(!PRE || NJ == 4, "written out for 4 column blocks per wave");
+            f16x8 ah[2], am[2], bh[4], bm[4];
+            ah[0] = fa(0, 0); bh[0] = fb(0, 0); bh[1] = fb(1, 0); bh[2] = fb(2, 0); bh[3] = fb(3, 0); ah[1] = fa(1, 0);
+            LKG_PIN();
+            LKG_MFMA(acc[0][0], ah[0], bh[0]); am[0] = fa(0, 1); LKG_PIN();
+            LKG_MFMA(acc[0][1], ah[0], bh[1]); am[1] = fa(1, 1); LKG_PIN();
+            LKG_MFMA(acc[0][2], ah[0], bh[2]); if (do_stage) p_shift1(); LKG_PIN();
+            LKG_MFMA(acc[0][3], ah[0], bh[3]); if (do_stage) p_shift2(); LKG_PIN();
+            LKG_MFMA(acc[1][0], ah[1], bh[0]); if (do_stage) p_mask(); LKG_PIN();
+            LKG_MFMA(acc[1][1], ah[1], bh[1]); LKG_PIN();
+            LKG_MFMA(acc[1][2], ah[1], bh[2]); if (do_stage) p_hi(); LKG_PIN();
+            LKG_MFMA(acc[1][3], ah[1], bh[3]); LKG_PIN();
+            LKG_MFMA(acc[0][0], am[0], bh[0]); if (do_stage) p_res(); LKG_PIN();
+            LKG_MFMA(acc[0][1], am[0], bh[1]); LKG_PIN();
+            LKG_MFMA(acc[0][2], am[0], bh[2]); if (do_stage) p_mid(); LKG_PIN();
+            LKG_MFMA(acc[0][3], am[0], bh[3]); LKG_PIN();
+            LKG_MFMA(acc[1][0], am[1], bh[0]); bm[0] = fb(0, 1); if (do_stage) p_write(); LKG_PIN();
+            LKG_MFMA(acc[1][1], am[1], bh[1]); bm[1] = fb(1, 1); LKG_PIN();
+            LKG_MFMA(acc[1][2], am[1], bh[2]); bm[2] = fb(2, 1); LKG_PIN();
+            LKG_MFMA(acc[1][3], am[1], bh[3]); bm[3] = fb(3, 1); LKG_PIN();
+            LKG_MFMA(acc[0][0], ah[0], bm[0]); LKG_PIN();
+            LKG_MFMA(acc[1][0], ah[1], bm[0]); LKG_PIN();
+            LKG_MFMA(acc[0][1], ah[0], bm[1]); LKG_PIN();
+            LKG_MFMA(acc[1][1], ah[1], bm[1]); LKG_PIN();
+            LKG_MFMA(acc[0][2], ah[0], bm[2]); LKG_PIN();
+            LKG_MFMA(acc[1][2], ah[1], bm[2]); LKG_PIN();
+            LKG_MFMA(acc[0][3], ah[0], bm[3]); LKG_PIN();
+            LKG_MFMA(acc[1][3], ah[1], bm[3]);
+        } else if constexpr (ONE) {
             LKG_MFMA(acc[0][0], a0[0], b0[0]); ahs[0] = a0[0] * sc; b1[0] = fb(0, 1); LKG_PIN();
             LKG_MFMA(acc[0][1], a0[0], b0[1]); ahs[1] = a0[1] * sc; b1[1] = fb(1, 1); LKG_PIN();
             LKG_MFMA(acc[1][0], a0[1], b0[0]); bhs[0] = b0[0] * sc; LKG_PIN();
@@ -501,8 +546,8 @@ void gemm_tall_kernel(TallArgs g) {
 #pragma unroll
         for (int q = 0; q < EPT; q += 4) {
             fp16x2 h0, m0_, h1, m1;
-            split2(ldexpf(e[q], ea), ldexpf(e[q + 1], ea), h0, m0_);
-            split2(ldexpf(e[q + 2], ea), ldexpf(e[q + 3], ea), h1, m1);
+            split2<PRE>(ldexpf(e[q], ea), ldexpf(e[q + 1], ea), h0, m0_);
+            split2<PRE>(ldexpf(e[q + 2], ea), ldexpf(e[q + 3], ea), h1, m1);
             typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
             const fp16x4 hv = {h0[0], h0[1], h1[0], h1[1]}, mv = {m0_[0], m0_[1], m1[0], m1[1]};
             *reinterpret_cast<fp16x4 *>(pa + q) = hv;
@@ -586,18 +631,18 @@ void gemm_tall_kernel(TallArgs g) {
             }
         };
         if constexpr (EPI == EPI_PLAIN) {
-            float bias_v[2];
-            int eb_v[2];
+            float bias_v[NJ];
+            int eb_v[NJ];
     #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                eb_v[j] = eb_s[wn * 64 + j * 32 + (lane & 31)];
-                bias_v[j] = bias_s[wn * 64 + j * 32 + (lane & 31)];
+            for (int j = 0; j < NJ; ++j) {
+                eb_v[j] = eb_s[wn * WN + j * 32 + (lane & 31)];
+                bias_v[j] = bias_s[wn * WN + j * 32 + (lane & 31)];
             }
     #pragma unroll
             for (int i = 0; i < 2; ++i)
     #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col0 = n0 + wn * 64 + j * 32;
+                for (int j = 0; j < NJ; ++j) {
+                    const int col0 = n0 + wn * WN + j * 32;
                     if (col0 >= g.n) continue;                                // wave-uniform
                     const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
                     float out[16];
@@ -613,14 +658,16 @@ void gemm_tall_kernel(TallArgs g) {
                     __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
                 }
         } else {
-            // gate: tile column block j = 0 holds g, j = 1 holds z of the SAME output column
+            // gate: of every pair of tile column blocks, block 2 pr holds g and block 2 pr + 1 holds z of the SAME output columns
             const int d = g.n / 2;
-            const int col0 = (n0 >> 1) + wn * 32;
+    #pragma unroll
+            for (int pr = 0; pr < NJ / 2; ++pr) {
+            const int col0 = (n0 >> 1) + wn * (WN / 2) + pr * 32;
             const int col = col0 + (lane & 31);
             if (col0 < d) {                                                   // wave-uniform
                 const int cc = min(col, d - 1);                               // lanes past d compute on a clamped column, never stored
-                const int ebg = eb_s[wn * 64 + (lane & 31)], ebz = eb_s[wn * 64 + 32 + (lane & 31)];
-                const float bg = bias_s[wn * 64 + (lane & 31)], bz = bias_s[wn * 64 + 32 + (lane & 31)];
+                const int ebg = eb_s[wn * WN + pr * 64 + (lane & 31)], ebz = eb_s[wn * WN + pr * 64 + 32 + (lane & 31)];
+                const float bg = bias_s[wn * WN + pr * 64 + (lane & 31)], bz = bias_s[wn * WN + pr * 64 + 32 + (lane & 31)];
     #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
@@ -645,10 +692,10 @@ void gemm_tall_kernel(TallArgs g) {
                             const int r = 8 * h + q;
                             const int dr = (r & 3) + 8 * (r >> 2);
                             const int e = ea_s[lr0 + dr];
-                            float gs = acc[i][0][r], zs = acc[i][1][r];
+                            float gs = acc[i][2 * pr][r], zs = acc[i][2 * pr + 1][r];
                             if constexpr (!ONE) {
-                                gs = fmaf(cor[i][0][r], 1.f / 2048.f, gs);
-                                zs = fmaf(cor[i][1][r], 1.f / 2048.f, zs);
+                                gs = fmaf(cor[i][2 * pr][r], 1.f / 2048.f, gs);
+                                zs = fmaf(cor[i][2 * pr + 1][r], 1.f / 2048.f, zs);
                             }
                             const float gp = ldexpf(gs, -(e + ebg)) + bg;
                             const float zp = ldexpf(zs, -(e + ebz)) + bz;
@@ -670,6 +717,7 @@ void gemm_tall_kernel(TallArgs g) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             }
         }
 
@@ -703,7 +751,7 @@ void gemm_tall_kernel(TallArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[i][j][r] = 0.f;
@@ -783,19 +831,16 @@ inline int total_ktiles(int n_panels, const int32_t *ka) {
 }
 // tile width and number of column tiles: the gate's stacked columns are interleaved in blocks of 32 (g, z, g, z ...), so
 // its stacked extent is 64 per 32 output columns
-// variant: LKG_TALL_VARIANT = "256x2" (two accumulators, 128 x 256 tiles), "128x1" / "256x1" (one accumulator)
-inline int tall_variant() {
-    static const int v = [] {
-        const char *e = getenv("LKG_TALL_VARIANT");
-        if (e && !strcmp(e, "256x2")) return 0;
-        if (e && !strcmp(e, "256x1")) return 2;
-        if (e && !strcmp(e, "128x1")) return 1;
-        return LKG_TALL_DEFAULT_VARIANT;
-    }();
-    return v;
+// variant: 0 "256x2" (two accumulators, 128 x 256 tiles), 1 "128x1", 2 "256x1" (one accumulator, 8 waves of 64 x 64),
+// 3 "256x1w" (one accumulator, prescaled mids, 4 waves of 64 x 128).  Chosen PER CALL: bits 8-15 of the `epilogue`
+// argument hold variant + 1 (0 = the library's default), so a test or a tool runs any variant next to any other in one
+// process and nothing in the environment selects code (LKG_TALL_VARIANT is gone).
+inline int variant_of(int epilogue_arg) {
+    const int v = (epilogue_arg >> 8) & 0xff;
+    return v == 0 ? LKG_TALL_DEFAULT_VARIANT : v - 1;
 }
-inline void geometry(int n, int epilogue, int &bn, int &tiles_n) {
-    const int v = tall_variant();
+inline void geometry(int n, int epilogue_arg, int &bn, int &tiles_n) {
+    const int v = variant_of(epilogue_arg), epilogue = epilogue_arg & 0xff;
     if (epilogue == EPI_GATE) {
         bn = v == 1 ? 128 : 256;
         tiles_n = ((n / 2 + 31) / 32 * 64 + bn - 1) / bn;
@@ -832,6 +877,10 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
                                  const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
                                  int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
                                  void *stream) {
+    const int32_t epilogue_arg = epilogue;          // bits 0-7: the epilogue, bits 8-15: variant + 1 (0 = default)
+    epilogue = epilogue_arg & 0xff;
+    LKG_REQUIRE((epilogue_arg >> 16) == 0 && ((epilogue_arg >> 8) & 0xff) <= 4, "lkg_gemm_tall_f32: unknown variant in the "
+                "epilogue argument (0x%x)", epilogue_arg);
     LKG_REQUIRE(m >= 0 && n > 0 && n_panels >= 1 && n_panels <= MAX_PANELS, "lkg_gemm_tall_f32: bad sizes");
     LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE, "lkg_gemm_tall_f32: unknown epilogue %d", epilogue);
     LKG_REQUIRE(n_groups == (epilogue == EPI_GATE ? 2 : 1), "lkg_gemm_tall_f32: the gate stacks 2 weight groups, a plain "
@@ -844,12 +893,14 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     LKG_REQUIRE(epilogue != EPI_GATE || (gate_x == a[0] && ld_x == lda[0] && ka[0] == d_out),
                 "lkg_gemm_tall_f32: the gate blends its FIRST K-panel (gate_x must be a[0], %d wide)", d_out);
     LKG_REQUIRE(ldc >= d_out, "lkg_gemm_tall_f32: ldc %lld smaller than the output width %d", (long long)ldc, d_out);
-    const int64_t need = lkg_gemm_tall_workspace(n, n_panels, ka, epilogue);
+    const int64_t need = lkg_gemm_tall_workspace(n, n_panels, ka, epilogue_arg);
     LKG_REQUIRE(workspace_bytes >= need, "lkg_gemm_tall_f32: workspace of %lld bytes is smaller than the %lld required",
                 (long long)workspace_bytes, (long long)need);
     hipStream_t s = (hipStream_t)stream;
     int bn, tiles_n;
-    geometry(n, epilogue, bn, tiles_n);
+    geometry(n, epilogue_arg, bn, tiles_n);
+    const int variant = variant_of(epilogue_arg);
+    const bool wide = variant == 3 && bn == 256;     // 4 waves of 64 x 128, prescaled mids
     TallArgs g{};
     BDesc bd{};
     g.m = m; g.n = n; g.n_panels = n_panels;
@@ -876,24 +927,26 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     const int n_stacked = g.tiles_n * bn;
     hipLaunchKernelGGL(b_exponent_kernel, dim3((n_stacked + 3) / 4), dim3(256), 0, s, bd, n_stacked, eb);
     if (bn == 256)
-        hipLaunchKernelGGL((b_planes_kernel<256>), dim3(g.tiles_n * g.ktiles_total), dim3(256), 0, s, bd, g.ktiles_total, eb, planes);
+        hipLaunchKernelGGL((b_planes_kernel<256>), dim3(g.tiles_n * g.ktiles_total), dim3(256), 0, s, bd, g.ktiles_total, eb, planes,
+                           wide ? 1 : 0);
     else
-        hipLaunchKernelGGL((b_planes_kernel<128>), dim3(g.tiles_n * g.ktiles_total), dim3(128), 0, s, bd, g.ktiles_total, eb, planes);
+        hipLaunchKernelGGL((b_planes_kernel<128>), dim3(g.tiles_n * g.ktiles_total), dim3(128), 0, s, bd, g.ktiles_total, eb, planes, 0);
     g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const long n_tiles_mn = (long)g.tiles_m * g.tiles_n;
-    auto lds_bytes = [](int bn_) {
+    auto lds_bytes = [](int bn_, int nt_) {
         return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4 +
-               (2 * bn_ + TM + 2 * bn_) * 4;       // + the landing area of the next tile's scalars
+               (nt_ + TM + 2 * bn_) * 4;       // + the landing area of the next tile's scalars
     };
-    const int lds = lds_bytes(bn);
-    const bool one = tall_variant() != 0;
-#define LKG_TALL_GO(BN_, EPI_, ONE_)                                                                                   \
+    const int lds = lds_bytes(bn, wide ? 256 : 2 * bn);
+    const bool one = variant != 0;
+#define LKG_TALL_GO(BN_, EPI_, ONE_) LKG_TALL_GO_W(BN_, EPI_, ONE_, 64)
+#define LKG_TALL_GO_W(BN_, EPI_, ONE_, WN_)                                                                                   \
     do {                                                                                                               \
         static bool raised = false;                                                                                    \
         static int resident = 0;      /* workgroups of this kernel the device holds at once (occupancy x CUs) */       \
         if (!raised && lds > 48 * 1024) {                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_>),                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_, WN_>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {                  \
                 lkg_set_error("lkg_gemm_tall_f32: cannot raise the dynamic LDS limit");                                \
                 return LKG_ERR_HIP;                                                                                    \
@@ -904,8 +957,9 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
             int dev_ = 0, per_cu_ = 0, cus_ = 0;                                                                       \
             if (hipGetDevice(&dev_) != hipSuccess ||                                                                   \
                 hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess ||             \
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_kernel<BN_, EPI_, ONE_>, 2 * BN_,     \
-                                                             lds) != hipSuccess || per_cu_ < 1 || cus_ < 1) {          \
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_kernel<BN_, EPI_, ONE_, WN_>,              \
+                                                             2 * (BN_ / WN_) * 64, lds) != hipSuccess ||               \
+                per_cu_ < 1 || cus_ < 1) {                                                                             \
                 lkg_set_error("lkg_gemm_tall_f32: cannot size the persistent grid");                                   \
                 return LKG_ERR_HIP;                                                                                    \
             }                                                                                                          \
@@ -916,11 +970,14 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
         /* several column tiles per row tile (the gate: 2): one workgroup per tile -- the workgroups of a row tile then \
            start together and the second one finds the A windows in the L2 (1.54 x the algorithmic traffic by the fabric \
            counters); persistent workgroups drift apart and every row tile's inputs cross the fabric twice (1.98 x) */   \
-        const bool one_tile_ = g.tiles_n > 1 || getenv("LKG_TALL_ONE_TILE") != nullptr;                                \
+        const bool one_tile_ = g.tiles_n > 1;                                                                          \
         const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
-        hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_>), grid, dim3(2 * BN_), lds, s, g);                       \
+        hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_, WN_>), grid, dim3(2 * (BN_ / WN_) * 64), lds, s, g);     \
     } while (0)
-    if (epilogue == EPI_GATE) {
+    if (wide) {
+        if (epilogue == EPI_GATE) LKG_TALL_GO_W(256, EPI_GATE, true, 128);
+        else LKG_TALL_GO_W(256, EPI_PLAIN, true, 128);
+    } else if (epilogue == EPI_GATE) {
         if (bn == 256 && !one) LKG_TALL_GO(256, EPI_GATE, false);
         else if (bn == 256) LKG_TALL_GO(256, EPI_GATE, true);
         else LKG_TALL_GO(128, EPI_GATE, true);
@@ -932,6 +989,7 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
         else LKG_TALL_GO(128, EPI_PLAIN, true);
     }
 #undef LKG_TALL_GO
+#undef LKG_TALL_GO_W
     LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
     return LKG_OK;
 }

@@ -581,12 +581,18 @@ def tall_ok(m: int, n: int, ks: Sequence[int], single_panel_too: bool = False) -
     return n * sum(ks) <= (1 << 22)
 
 
+TALL_VARIANTS = {"256x2": 0, "128x1": 1, "256x1": 2, "256x1w": 3}      # lkg_gemm_tall_f32: bits 8-15 of `epilogue` = id + 1
+DEFAULT_TALL_VARIANT: Optional[str] = None      # None = the library's default; tests / tools set a key to steer whole modules
+
+
 def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torch.Tensor]], trans_b: bool,
               bias: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
-              out: Optional[torch.Tensor] = None, rowmax: Optional[torch.Tensor] = None, gate_x=None, keep=None):
+              out: Optional[torch.Tensor] = None, rowmax: Optional[torch.Tensor] = None, gate_x=None, keep=None,
+              variant: Optional[str] = None):
     """C = sum_p a_panels[p] @ op(B_p) (+ bias) for a tall A (lkg_gemm_tall_f32).  b_blocks[g][p]: block of B for row
     group g (1 group; 2 = the gate's stacked g / z projections with the blend epilogue on gate_x) and panel p; trans_b:
-    blocks stored [n, k_p] (nn.Linear weights) else [k_p, n].  keep = (g_out, z_out) for the gate's backward."""
+    blocks stored [n, k_p] (nn.Linear weights) else [k_p, n].  keep = (g_out, z_out) for the gate's backward.
+    variant: None = the library's default tiling, or a key of TALL_VARIANTS (tests and tools run them side by side)."""
     if rowmax is None:
         rowmax = rows_absmax(a_panels)          # (before any .contiguous(): the producers' tags live on these objects)
     a_panels = [_f32_rows(a) for a in a_panels]
@@ -628,7 +634,8 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
     flat = [b for grp in blocks for b in grp]
     b_ptr = (_C.c_void_p * len(flat))(*[b.data_ptr() for b in flat])
     b_ld = (_C.c_int64 * len(flat))(*[_ld(b) for b in flat])
-    epi = 1 if gate else 0
+    variant = variant if variant is not None else DEFAULT_TALL_VARIANT
+    epi = (1 if gate else 0) | (0 if variant is None else (TALL_VARIANTS[variant] + 1) << 8)
     need = N.load().lkg_gemm_tall_workspace(n, np_, a_k, epi)
     ws = _workspace(int(need), out.device)
     gx = _f32_rows(gate_x) if gate else None

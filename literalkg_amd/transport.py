@@ -218,3 +218,19 @@ class InFlight:
 def drain_on_error(device: Optional[torch.device] = None):
     """Context manager for drivers (bench.py, tools/): an exception leaves only after the device is idle."""
     return InFlight(device)
+
+
+def install_drain_excepthook():
+    """For scripts (tools/, examples/): an uncaught exception first drains the device, then is reported as usual -- the
+    interpreter releases every tensor right after, and a kernel still queued on a side stream must not outlive them."""
+    import sys
+    previous = sys.excepthook
+
+    def hook(exc_type, exc, tb):
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:   # noqa: BLE001
+            pass
+        previous(exc_type, exc, tb)
+    sys.excepthook = hook

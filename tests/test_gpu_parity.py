@@ -327,6 +327,59 @@ def test_gemm_tall_f16x2_engine_is_f32_accurate(ops, gpu_device, ks, n, tb):
     assert err4 <= max(10.0 * f32, 5e-6), (err4, f32)
 
 
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "128x1"])
+@pytest.mark.parametrize("ks,n,tb", [((256,), 256, True), ((256, 2, 300), 256, True), ((512,), 300, True), ((30, 7), 50, False),
+                                     ((40,), 200, True)])
+def test_gemm_tall_every_tiling_variant_is_f32_accurate(ops, gpu_device, variant, ks, n, tb):
+    """Every tiling of lkg_gemm_tall_f32 (bits 8-15 of its `epilogue` argument) against float64 on the same operands: the
+    two-accumulator form, the 8-wave and the 4-wave (64 x 128 wave tiles, prescaled mids) one-accumulator forms and the
+    128-column form -- plain product, alpha / beta / bias into a strided output, rows of very different magnitude."""
+    gen = torch.Generator().manual_seed(sum(ks) * 1000 + n + 7)
+    m = 16384 + 131
+    panels = [torch.randn(m, k + 1, generator=gen)[:, 1:].to(gpu_device) if i % 2 else torch.randn(m, k, generator=gen).to(gpu_device)
+              for i, k in enumerate(ks)]
+    blocks = [(torch.randn((n, k) if tb else (k, n), generator=gen) * 0.1).to(gpu_device) for k in ks]
+    a64 = torch.cat([p.double() for p in panels], 1)
+    b64 = torch.cat([b.double() if tb else b.double().t() for b in blocks], 1)
+    want = a64 @ b64.t()
+    scale = float(want.abs().max())
+    f32 = float(((a64.float() @ b64.float().t()).double() - want).abs().max()) / scale
+    got = ops.gemm_tall(panels, (blocks,), tb, variant=variant)
+    err = float((got.double() - want).abs().max()) / scale
+    assert err <= max(3.0 * f32, 1e-6), (variant, err, f32)
+    bias = torch.randn(n, generator=gen).to(gpu_device)
+    c0 = torch.randn(m, n + 5, generator=gen).to(gpu_device)[:, 5:]
+    got2 = ops.gemm_tall(panels, (blocks,), tb, bias, alpha=0.5, beta=2.0, out=c0.clone(), variant=variant)
+    torch.testing.assert_close(got2.double(), 0.5 * want + 2.0 * c0.double() + bias.double(), rtol=1e-5, atol=4e-6 * scale)
+    mags = torch.pow(torch.tensor(10.0), torch.randint(-30, 30, (m, 1), generator=gen).float()).to(gpu_device)
+    mags[9] = 0.0
+    scaled = [p * mags for p in panels]
+    got3 = ops.gemm_tall(scaled, (blocks,), tb, variant=variant)
+    want3 = torch.cat([p.double() for p in scaled], 1) @ b64.t()
+    rel = (got3.double() - want3).abs() / want3.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    assert float(rel.max()) <= max(30.0 * f32, 1e-5), (variant, float(rel.max()))
+    assert float(got3[9].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w"])
+def test_fused_gate_every_tiling_variant(L, ops, O, gpu_device, variant):
+    """The gate's one-launch stacked product (blend epilogue) on every 256-column tiling against the oracle's gate."""
+    torch.manual_seed(4)
+    n, d = 16384 + 77, 300
+    old = ops.DEFAULT_TALL_VARIANT
+    ops.DEFAULT_TALL_VARIANT = variant
+    try:
+        gate = L.gate.GateMul(d, 2, 300).to(gpu_device)
+        x = (torch.randn(n, d) * 0.3).to(gpu_device)
+        num, txt = torch.rand(n, 2).to(gpu_device), torch.randn(n, 300).to(gpu_device)
+        got = gate(x, num, txt)
+        sd = {k: v.detach().cpu() for k, v in gate.state_dict().items()}
+        want = O.gate_mul(sd, "", x.cpu(), num.cpu(), txt.cpu())
+    finally:
+        ops.DEFAULT_TALL_VARIANT = old
+    torch.testing.assert_close(got.cpu(), want.float(), rtol=1e-4, atol=2e-5)
+
+
 def test_fused_gate_matches_oracle_and_the_unfused_path(L, ops, O, gpu_device):
     """GateMul / Gate through the one-launch stacked GEMM with the blend epilogue (rows >= 16384) against the oracle's
     gate (forward, input gradient, every weight gradient), with literal widths that are not multiples of 4."""

@@ -29,16 +29,20 @@ def test_no_kernel_spills_or_uses_scratch(src):
 
 
 def test_tall_gemm_keeps_two_workgroups_per_cu():
-    """The one-accumulator 256-column tall kernels (plain AND gate epilogue) are built for two 8-wave workgroups per CU:
-    at most 128 VGPRs (4 waves per SIMD) -- with one workgroup per CU the k loop of the gate left the matrix pipe 38 %
-    busy.  Their LDS (76 KB each) is dynamic and set by the launcher."""
+    """The one-accumulator 256-column tall kernels (plain AND gate epilogue) are built for two workgroups per CU: the 8-wave
+    form (64 x 64 wave tiles) at most 128 VGPRs (4 waves per SIMD), the 4-wave form (64 x 128 wave tiles) at most 256
+    (2 waves per SIMD) -- with one workgroup per CU the k loop of the gate left the matrix pipe 38 % busy.
+    Their LDS (76-79 KB each) is dynamic and set by the launcher."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     asm = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", "-",
                           os.path.join(CSRC, "lkg_gemm_tall.hip")], check=True, capture_output=True, text=True).stdout
     found = {}
-    for name, vgpr in re.findall(r"\.name:\s+(\S*gemm_tall_kernelILi256ELi[01]ELb1E\S*)\n(?:.*\n)*?.*?\.vgpr_count:\s+(\d+)", asm):
+    for name, vgpr in re.findall(r"\.name:\s+(\S*gemm_tall_kernelILi256ELi[01]ELb1ELi(?:64|128)E\S*)\n(?:.*\n)*?.*?\.vgpr_count:\s+(\d+)", asm):
         found[name] = int(vgpr)
-    assert len(found) == 2, found
-    assert all(v <= 128 for v in found.values()), found
+    narrow = {k: v for k, v in found.items() if "ELb1ELi64E" in k}
+    wide = {k: v for k, v in found.items() if "ELb1ELi128E" in k}
+    assert len(narrow) == 2 and len(wide) == 2, found
+    assert all(v <= 128 for v in narrow.values()), narrow
+    assert all(v <= 256 for v in wide.values()), wide

@@ -24,6 +24,9 @@ import __graft_entry__ as ge
 
 ge.build()
 import literalkg_amd as L
+from literalkg_amd.transport import install_drain_excepthook
+
+install_drain_excepthook()      # an uncaught exception drains the device before the interpreter releases the tensors
 from literalkg_amd import ops
 from literalkg_amd.sharding import FeatureShardedAggregation, shard_bounds
 from literalkg_amd.synth import make_kg_device

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.build()
 import literalkg_amd as L
+from literalkg_amd.transport import install_drain_excepthook
+
+install_drain_excepthook()      # an uncaught exception drains the device before the interpreter releases the tensors
 from literalkg_amd import ops
 from literalkg_amd.synth import make_kg, xavier_table
 
