@@ -551,6 +551,11 @@ int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t
  *                      its values are kept on chip while they pass through the staging registers) with tanh(g) / sigmoid(z)
  *                      optionally kept in gate_g / gate_z for lkg_gate_blend_bwd_f32(activated = 1);
  *   epilogue 0         C = alpha * product + beta * C + bias[n];
+ *   epilogue bits 8-15 the tiling, chosen per call: 0 = the library's default, else 1 + {0 "256x2", 1 "128x1", 2 "256x1",
+ *                      3 "256x1w", 4 "ws"} (tests and tools run them side by side; nothing in the environment selects code).
+ *                      "ws" is the wave-specialised form: one 8-wave workgroup per CU, four loader waves keep the raw A windows
+ *                      of up to six k steps in flight through an LDS ring (across tile boundaries) and split them into fp16
+ *                      planes, four compute waves of 64 x 128 stream B's planes, run the MFMAs and the epilogue;
  *   workspace          >= lkg_gemm_tall_workspace(n, n_panels, ka, epilogue) bytes (B's fp16 planes: no allocation here). */
 int lkg_row_absmax_f32(int64_t n, int32_t d, const float *x, int64_t ldx, float *out, int32_t accumulate,
                        void *stream);
@@ -561,6 +566,24 @@ int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const
                       const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
                       int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
                       void *stream);
+
+/* K5 as surveyed ("fused epilogue around an MFMA GEMM"): an aggregation layer's whole dense part in ONE launch,
+ *     z  = sum_p A_p W_p^T + bias                      (nn.Linear over a column-concatenated input, model.py:108-110, 116-123)
+ *     y  = Dropout_p(LayerNorm(LeakyReLU_slope(z)))    (model.py:111, 161; eps, gamma, beta: nn.LayerNorm's)
+ *     yn = y / max(|y|_2, norm_eps)                    (F.normalize, model.py:305)
+ * for output widths n <= 256: the 128 x 256 tile of the wave-specialised tall GEMM holds whole rows, the row statistics are
+ * three sums exchanged between the two compute waves of a row.  z is NOT written (nor read back by a second kernel): one HBM
+ * pass fewer than lkg_gemm_tall_f32 + lkg_act_layernorm_fwd_f32, which it matches to fp32 rounding (the sums run in another
+ * order).  y and yn are nullable (not both); save_mean / save_rstd float[m] are what lkg_act_layernorm_bwd_f32 needs beside a
+ * recomputed z.  The dropout mask is lkg_act_layernorm_fwd_f32's (same seed, same mask).  Arguments a .. a_rowmax, workspace:
+ * as for lkg_gemm_tall_f32 (w: one [n, ka[p]] block per panel, nn.Linear layout).                                         */
+int64_t lkg_linear_act_layernorm_workspace(int32_t n, int32_t n_panels, const int32_t *ka);
+int lkg_linear_act_layernorm_fwd_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
+                                     const int32_t *ka, const float *a_rowmax, const float *const *w, const int64_t *ldw,
+                                     const float *bias, float slope, const float *gamma, const float *beta, float eps,
+                                     float *y, int64_t ldy, float *yn, int64_t ldyn, float norm_eps, float *save_mean,
+                                     float *save_rstd, float drop_p, uint64_t seed, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,9 @@ PROTOTYPES = {
     "lkg_gemm_tall_workspace": [i32, i32, vp, i32],
     "lkg_gemm_tall_f32": [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, i64, vp, i32, vp, i64, vp, i64,
                           vp, i64, vp, i64, vp],
+    "lkg_linear_act_layernorm_workspace": [i32, i32, vp],
+    "lkg_linear_act_layernorm_fwd_f32": [i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, f32, vp, i64, vp, i64, f32,
+                                         vp, vp, f32, u64, vp, i64, vp],
     "lkg_gemm_workspace": [i32, i64, i64, i64],
     "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i64, vp],
     "lkg_colsum_f32": [i64, i32, vp, i64, vp, vp],
@@ -87,6 +90,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"lkg_last_error": C.c_char_p, "lkg_csr_build_device_workspace": C.c_int64,
             "lkg_gemm_tall_workspace": C.c_int64, "lkg_gemm_workspace": C.c_int64,
+            "lkg_linear_act_layernorm_workspace": C.c_int64,
             "lkg_csr_transpose_device_workspace": C.c_int64}
 
 

@@ -93,6 +93,25 @@ __device__ __forceinline__ void f4_fma(float4 &a, float s, const float4 &x) {
     a.w = fmaf(s, x.w, a.w);
 }
 
+// Counter-based dropout mask: keep(seed, row, col) is a pure function (two rounds of the murmur3 32-bit
+// finaliser), so the backward regenerates the mask instead of storing it.  torch's Philox stream cannot be
+// reproduced from outside ATen, so training-mode parity with the reference is statistical.
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ unsigned drop_row_key(unsigned long long seed, unsigned long long row) {
+    return fmix32((unsigned)seed ^ fmix32((unsigned)row * 0x9E3779B1u + (unsigned)(row >> 32) + (unsigned)(seed >> 32)));
+}
+__device__ __forceinline__ float drop_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
+    const unsigned h = fmix32(row_key ^ (col * 0x27D4EB2Fu + 0x165667B1u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
+}
+
+
 // numerically safe -logsigmoid(x) = softplus(-x), the form ATen uses:
 // -(min(x,0) - log1p(exp(-|x|)))
 __device__ __forceinline__ float neg_logsigmoid(float x) {

@@ -32,13 +32,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "lkg_common.h"
 
 namespace {
 
 #ifndef LKG_TALL_DEFAULT_VARIANT
-#define LKG_TALL_DEFAULT_VARIANT 3      /* 0 "256x2", 1 "128x1", 2 "256x1" (8 waves of 64 x 64), 3 "256x1w" (4 waves of 64 x 128) */
+#define LKG_TALL_DEFAULT_VARIANT 2      /* 0 "256x2", 1 "128x1", 2 "256x1" (8 waves of 64 x 64), 3 "256x1w" (4 waves of 64 x 128) */
 #endif
 constexpr int TM = 128, TK = 16, MAX_PANELS = 3;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -46,7 +47,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_PLAIN = 0, EPI_GATE = 1 };
+enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_ACTLN = 2 };
 
 struct TallArgs {
     long m;
@@ -70,6 +71,14 @@ struct TallArgs {
     float *g_out, *z_out;        // nullable: tanh(g) / sigmoid(z) kept for the backward
     long ldg, ldz;
     int tiles_m, tiles_n;
+    // act + LayerNorm epilogue (EPI_ACTLN, one column tile: n <= 256): y = Dropout(LayerNorm(LeakyReLU(A B^T + bias))) -> c
+    // (nullable), yn = y / max(|y|_2, norm_eps) -> yn (nullable), the row statistics the backward needs -> mean / rstd
+    float slope, ln_eps, norm_eps, drop_p;
+    unsigned long long seed;
+    const float *gamma, *beta_ln;
+    float *yn;
+    long ldyn;
+    float *mean, *rstd;
 };
 
 // exponent e with max * 2^e in [2^13, 2^14)   (0 for max == 0 / denormal; clamped so that ldexp stays finite)
@@ -804,6 +813,650 @@ void gemm_tall_kernel(TallArgs g) {
 #undef LKG_WAIT_BARRIER
 }
 
+
+// =====================================================================================================================
+// Wave-specialised form (variant 4, "ws"): ONE 8-wave workgroup per CU, 128 x 256 tiles, two kinds of waves.
+//
+// Why.  `s_waitcnt vmcnt(N)` retires a wave's memory operations in ISSUE order, loads and LDS-DMAs alike.  In the forms
+// above every wave requests both operands, so the wait for B's planes of the next step (an L2 hit, requested one step
+// ago) also waits for every A window requested before them: whatever the depth of A's ring, a window has TWO steps to
+// come back from HBM.  Measured (tools/tall_variants_micro.py, round 4): the k loop costs ~1800 cycles per tile and step
+// on a CU whichever way its waves are arranged (8 waves of 64 x 64 or 4 of 64 x 128) -- the matrix pipe 43 % busy, 2.2 TB/s
+// of A: a latency bound, bytes in flight = 2 steps x 8 KB per workgroup.  Here the two streams live in different waves:
+//
+//   waves 4-7 "loaders"   the A stream.  Every thread requests its own two 16-byte windows of the raw f32 tile (and its
+//                         row's maximum) by LDS-DMA into a ring of WS_R slots, R - 1 items ahead -- across tile
+//                         boundaries: the ring keeps filling while the compute waves store the previous tile --, reads
+//                         its own pieces back, splits them (hi / prescaled mid, split2<true>) and writes its piece of
+//                         the fp16 planes of the NEXT step.  They issue nothing but A requests, so their counted wait
+//                         (vmcnt(3 (R - 2))) leaves R - 2 items in flight: 48 KB per CU with R = 8.
+//   waves 0-3 "compute"   64 x 128 each (one per SIMD): B's ready-made planes by LDS-DMA into a ring of 3 buffers two steps
+//                         ahead (their only requests besides the epilogue's stores), fragment reads, 24 MFMAs per step,
+//                         the epilogue.  No VALU work of the split competes with their MFMA issue.
+//
+// One workgroup barrier per k step orders everything: before barrier g the loaders have written A's planes of step g and
+// every compute wave has its pieces of B(g) in; after it the compute waves read planes g while the loaders overwrite the
+// buffers of step g - 1.  Items (tile, k tile) form ONE stream over the tiles of the workgroup; a row tile's column tiles
+// (the gate: 2) are consecutive items, so the second one reads A from the L2 its own CU has just filled.
+constexpr int WS_R = 8, WS_NB = 3;
+constexpr int WS_APL = TM * TK, WS_BPL = 256 * TK;                 // halves per plane
+constexpr int WS_SLOT_BYTES = TM * TK * 4 + 1024;                  // raw A tile + one row maximum per loader thread
+constexpr int WS_OFF_A = 0;                                        // 2 x [hi | mid']             16 KB
+constexpr int WS_OFF_B = WS_OFF_A + 2 * 2 * WS_APL * 2;            // 3 x [hi | mid']             48 KB
+constexpr int WS_OFF_RING = WS_OFF_B + WS_NB * 2 * WS_BPL * 2;     // R slots                     72 KB
+constexpr int WS_OFF_TS = WS_OFF_RING + WS_R * WS_SLOT_BYTES;      // 4 x 4 KB epilogue transposes 16 KB
+constexpr int WS_OFF_EA = WS_OFF_TS + 4 * 4096;                    // int[2][128] row exponents, by tile parity
+constexpr int WS_OFF_ST = WS_OFF_EA + 2 * TM * 4;                  // float[3][2][128] row statistics (EPI_ACTLN)
+constexpr int WS_OFF_COL = WS_OFF_ST + 3 * 2 * TM * 4;             // [4][256] per-column scalars (EPI_ACTLN: exponent, bias, gamma, beta)
+constexpr int WS_LDS_BYTES = WS_OFF_COL + 4 * 256 * 4;
+static_assert(WS_LDS_BYTES <= 160 * 1024, "one workgroup per CU: at most 160 KB of LDS");
+
+struct WsWalk {            // position in the item stream: row tile (index into this workgroup's stripe), column tile, k tile
+    int rt, tn, panel, tk, gt;
+};
+
+// In-kernel stamps (a DIAGNOSTIC build only: LKG_EXTRA_HIPCC_FLAGS=-DLKG_WS_STAMPS; tools/ws_stamps.py): every wave sums the
+// cycles it spends waiting for memory, waiting at the step barrier and working; lane 0 adds the sums to the buffer the
+// caller hands in as the gate's (otherwise unused) z_out of a PLAIN product.  No stamp executes in the product build.
+#ifdef LKG_WS_STAMPS
+#define LKG_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LKG_STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define LKG_STAMP(var)
+#define LKG_STAMP_ADD(acc, a, b)
+#endif
+
+// Position in the item stream, advanced by one item.  (Plain functions with value / reference parameters instead of lambdas
+// capturing by reference: with the loader written as lambdas hipcc kept 39 closures and their captured variables in scratch.)
+struct WsShape {
+    int n_rt, tiles_n, kt_total, kt0, kt1, kt2;
+};
+// (the shape BY VALUE: a select between fields of a struct behind a reference becomes a runtime index into a private copy)
+__device__ __forceinline__ void ws_advance(WsWalk &w, const WsShape sh) {         // (past the last item: stays there -- duplicates)
+    const int n_rt = sh.n_rt, tiles_n = sh.tiles_n, kt_total = sh.kt_total, kt0 = sh.kt0, kt1 = sh.kt1, kt2 = sh.kt2;
+    if (w.rt == n_rt - 1 && w.tn == tiles_n - 1 && w.gt == kt_total - 1) return;
+    if (w.gt + 1 < kt_total) {
+        ++w.gt;
+        int nt = kt0;
+        if (w.panel == 1) nt = kt1;
+        if (w.panel == 2) nt = kt2;
+        if (++w.tk == nt) { w.tk = 0; ++w.panel; }
+    } else {
+        w.gt = 0; w.tk = 0; w.panel = 0;
+        if (++w.tn == tiles_n) { w.tn = 0; ++w.rt; }
+    }
+}
+
+// ======================================================================================= loaders: the A stream (waves 4-7)
+// (a loader's step must stay under the compute waves' 768 MFMA cycles: everything per item is incremental -- row pointers per
+//  row tile, a 64-byte step per k tile -- and the rare cases, windows moved back at the end of the LAST row and the partial
+//  last k tile of a panel, sit behind wave-uniform branches)
+template <int EPI>
+__device__ __forceinline__ void ws_loader(const TallArgs &g, char *lds, const int lt, const int lw, const int n_rt,
+                                          const int n_items, const int tile0, const int slot_stride) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef __attribute__((address_space(1))) const float4u gf4;
+    typedef __attribute__((address_space(1))) const unsigned gu1;
+    const WsShape shp{n_rt, g.tiles_n, g.ktiles_total, g.ktiles[0], g.ktiles[1], g.ktiles[2]};
+    const int arow = lt >> 1, akc = lt & 1;                            // this thread's row of the tile / 8-float chunk of the k tile
+    // (absent panels: the launcher leaves their fields zero; their addresses are computed and never used)
+    const unsigned long pa0 = reinterpret_cast<unsigned long>(g.a[0]);
+    const unsigned long pa1 = reinterpret_cast<unsigned long>(g.a[1]);
+    const unsigned long pa2 = reinterpret_cast<unsigned long>(g.a[2]);
+    const long ld0 = g.lda[0], ld1 = g.lda[1], ld2 = g.lda[2];
+    const int kw0 = g.ka[0], kw1 = g.ka[1], kw2 = g.ka[2];
+    // the last valid 16-byte window of every panel (of the LAST row: only windows past it are moved back)
+    const unsigned long lastw0 = pa0 + 4ul * (unsigned long)((g.m - 1) * ld0 + kw0 - 4);
+    const unsigned long lastw1 = pa1 + 4ul * (unsigned long)((g.m - 1) * ld1 + kw1 - 4);
+    const unsigned long lastw2 = pa2 + 4ul * (unsigned long)((g.m - 1) * ld2 + kw2 - 4);
+    unsigned long rowp0 = 0, rowp1 = 0, rowp2 = 0;                     // this thread's chunk of its row, per panel (per row tile)
+    WsWalk fw{0, 0, 0, 0, 0}, sw{0, 0, 0, 0, 0}, cw{0, 0, 0, 0, 0};   // issue / stage walks; cw: the item the compute waves work on
+    unsigned sh_fifo = 0;                                              // 4 bits per item in flight: how far its two windows were moved back
+    int ea = 0;
+
+    // item fw -> ring slot
+#define LKG_WS_ISSUE(SLOT)                                                                                                 \
+    do {                                                                                                                   \
+        char *dst_ = lds + WS_OFF_RING + (SLOT) * WS_SLOT_BYTES;                                                           \
+        if (fw.gt == 0 && fw.tn == 0) {          /* (wave-uniform) a new row tile: row pointers, row maximum */            \
+            const long row_ = min((long)(tile0 + fw.rt * slot_stride) * TM + arow, g.m - 1);                               \
+            rowp0 = pa0 + 4ul * (unsigned long)(row_ * ld0 + akc * 8);                                                     \
+            rowp1 = pa1 + 4ul * (unsigned long)(row_ * ld1 + akc * 8);                                                     \
+            rowp2 = pa2 + 4ul * (unsigned long)(row_ * ld2 + akc * 8);                                                     \
+            __builtin_amdgcn_global_load_lds((gu1 *)(g.a_rowmax + row_), (lds_void *)(dst_ + 8192 + lw * 256), 4, 0, 0);   \
+        }                                                                                                                  \
+        const unsigned long rowp_ = fw.panel == 0 ? rowp0 : (fw.panel == 1 ? rowp1 : rowp2);                               \
+        const unsigned long lastw_ = fw.panel == 0 ? lastw0 : (fw.panel == 1 ? lastw1 : lastw2);                           \
+        const unsigned long want_ = rowp_ + (unsigned long)(fw.tk * (TK * 4));                                             \
+        const unsigned long p0_ = want_ < lastw_ ? want_ : lastw_;                                                         \
+        const unsigned long p1_ = want_ + 16 < lastw_ ? want_ + 16 : lastw_;                                               \
+        sh_fifo |= (((unsigned)((want_ - p0_) >> 2) & 3u) | (((unsigned)((want_ + 16 - p1_) >> 2) & 3u) << 2))             \
+                   << (4 * (WS_R - 2));                                                                                    \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gf4 *>(p0_), (lds_void *)(dst_ + lw * 1024), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<gf4 *>(p1_), (lds_void *)(dst_ + 4096 + lw * 1024), 16, 0, 0);   \
+        ws_advance(fw, shp);                                                                                               \
+    } while (0)
+
+    // item sw: ring slot -> this thread's piece of the planes of buffer ABUF
+#define LKG_WS_STAGE(SLOT, ABUF)                                                                                           \
+    do {                                                                                                                   \
+        const unsigned base_ = (unsigned)(unsigned long)(lds_void *)(lds + WS_OFF_RING + (SLOT) * WS_SLOT_BYTES);          \
+        f32x4 v0, v1;                                                                                                      \
+        /* (inline asm: a ds_read hipcc can see makes it wait for EVERY LDS-DMA in flight) */                              \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(base_ + lt * 16) : "memory");                                  \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v1) : "v"(base_ + 4096 + lt * 16) : "memory");                           \
+        if (sw.gt == 0 && sw.tn == 0) {          /* (wave-uniform) a new row tile: this thread's row exponent */           \
+            float rmv_;                                                                                                    \
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rmv_) : "v"(base_ + 8192 + lt * 4) : "memory"); \
+            ea = scale_exponent(rmv_);                                                                                     \
+        }                                                                                                                  \
+        if (sw.gt == 0 && akc == 0)              /* the tile's row exponents for the compute waves' epilogue */            \
+            reinterpret_cast<int *>(lds + WS_OFF_EA)[((sw.rt * g.tiles_n + sw.tn) & 1) * TM + arow] = ea;                   \
+        const unsigned sh_ = sh_fifo & 15u;                                                                                \
+        sh_fifo >>= 4;                                                                                                     \
+        const int kw_ = sw.panel == 0 ? kw0 : (sw.panel == 1 ? kw1 : kw2);                                                 \
+        const int k0_ = sw.tk * TK + akc * 8;                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1) :: "memory");                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        float e0 = v0[0], e1 = v0[1], e2 = v0[2], e3 = v0[3], e4 = v1[0], e5 = v1[1], e6 = v1[2], e7 = v1[3];              \
+        if (__builtin_amdgcn_ballot_w64(sh_ != 0) != 0) {   /* (rare: the end of the panel's last row) windows moved back:   \
+            element u of a window moved back by s elements sits at v[u + s]; past the loaded four: beyond the panel (0) */   \
+            const int s0 = sh_ & 3, s1 = sh_ >> 2;                                                                         \
+            e0 = s0 == 0 ? v0[0] : (s0 == 1 ? v0[1] : (s0 == 2 ? v0[2] : v0[3]));                                          \
+            e1 = s0 == 0 ? v0[1] : (s0 == 1 ? v0[2] : (s0 == 2 ? v0[3] : 0.f));                                            \
+            e2 = s0 == 0 ? v0[2] : (s0 == 1 ? v0[3] : 0.f);                                                                \
+            e3 = s0 == 0 ? v0[3] : 0.f;                                                                                    \
+            e4 = s1 == 0 ? v1[0] : (s1 == 1 ? v1[1] : (s1 == 2 ? v1[2] : v1[3]));                                          \
+            e5 = s1 == 0 ? v1[1] : (s1 == 1 ? v1[2] : (s1 == 2 ? v1[3] : 0.f));                                            \
+            e6 = s1 == 0 ? v1[2] : (s1 == 1 ? v1[3] : 0.f);                                                                \
+            e7 = s1 == 0 ? v1[3] : 0.f;                                                                                    \
+        }                                                                                                                  \
+        if (sw.tk * TK + TK > kw_) {             /* (wave-uniform) the panel's partial last k tile: columns past it are 0 */ \
+            e0 = k0_ + 0 < kw_ ? e0 : 0.f; e1 = k0_ + 1 < kw_ ? e1 : 0.f; e2 = k0_ + 2 < kw_ ? e2 : 0.f;                    \
+            e3 = k0_ + 3 < kw_ ? e3 : 0.f; e4 = k0_ + 4 < kw_ ? e4 : 0.f; e5 = k0_ + 5 < kw_ ? e5 : 0.f;                    \
+            e6 = k0_ + 6 < kw_ ? e6 : 0.f; e7 = k0_ + 7 < kw_ ? e7 : 0.f;                                                  \
+        }                                                                                                                  \
+        fp16x2 h0, h1, h2, h3, m0_, m1_, m2_, m3_;                                                                         \
+        split2<true>(ldexpf(e0, ea), ldexpf(e1, ea), h0, m0_);                                                             \
+        split2<true>(ldexpf(e2, ea), ldexpf(e3, ea), h1, m1_);                                                             \
+        split2<true>(ldexpf(e4, ea), ldexpf(e5, ea), h2, m2_);                                                             \
+        split2<true>(ldexpf(e6, ea), ldexpf(e7, ea), h3, m3_);                                                             \
+        _Float16 *pa_ = reinterpret_cast<_Float16 *>(lds + WS_OFF_A) + (ABUF) * (2 * WS_APL) + arow * TK +                 \
+                        ((akc ^ ((arow >> 4) & 1)) << 3);                                                                  \
+        typedef __fp16 fp16x8 __attribute__((ext_vector_type(8)));                                                         \
+        const fp16x8 hv_ = {h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};                                       \
+        const fp16x8 mv_ = {m0_[0], m0_[1], m1_[0], m1_[1], m2_[0], m2_[1], m3_[0], m3_[1]};                               \
+        *reinterpret_cast<fp16x8 *>(pa_) = hv_;                                                                            \
+        *reinterpret_cast<fp16x8 *>(pa_ + WS_APL) = mv_;                                                                   \
+        ws_advance(sw, shp);                                                                                               \
+    } while (0)
+
+    // 2 window requests per item (+ 1 row maximum per row tile): "all but the 12 youngest" leaves WS_R - 2 items in flight --
+    // a row maximum among them only makes the wait ask for a little more than it needs
+#define LKG_WS_WAIT_A() asm volatile("s_waitcnt vmcnt(12)" ::: "memory")
+    static_assert(2 * (WS_R - 2) == 12, "the counted wait above");
+#pragma unroll
+    for (int i = 0; i < WS_R - 1; ++i) {
+        sh_fifo >>= 4;                                                 // (the prologue fills the queue from the top: entry i ends at position i)
+        LKG_WS_ISSUE(i);
+    }
+    LKG_WS_WAIT_A();
+    LKG_WS_STAGE(0, 0);
+    int slot_issue = WS_R - 1, slot_stage = 1;
+#ifdef LKG_WS_STAMPS
+    unsigned long long t_bar = 0, t_issue = 0, t_mem = 0, t_stage = 0;
+#endif
+    for (int it = 0; it < n_items; ++it) {
+        LKG_STAMP(s0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this thread's plane writes of item `it`
+        asm volatile("s_barrier" ::: "memory");                        // ---- barrier `it`
+        LKG_STAMP(s1);
+        LKG_WS_ISSUE(slot_issue);                                      // item it + R - 1 into the slot item it - 1 left
+        LKG_STAMP(s2);
+        LKG_WS_WAIT_A();                                               // item it + 1 is in
+        LKG_STAMP(s3);
+        LKG_WS_STAGE(slot_stage, (it + 1) & 1);
+        LKG_STAMP(s4);
+        LKG_STAMP_ADD(t_bar, s0, s1); LKG_STAMP_ADD(t_issue, s1, s2); LKG_STAMP_ADD(t_mem, s2, s3); LKG_STAMP_ADD(t_stage, s3, s4);
+        if constexpr (EPI == EPI_ACTLN) {                              // the compute waves' six statistics exchanges of a tile end
+            if (cw.gt == shp.kt_total - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int b6 = 0; b6 < 6; ++b6) asm volatile("s_barrier" ::: "memory");       // (three per row half)
+            }
+            ws_advance(cw, shp);
+        }
+        slot_issue = slot_issue == WS_R - 1 ? 0 : slot_issue + 1;
+        slot_stage = slot_stage == WS_R - 1 ? 0 : slot_stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // nothing may land in the LDS of a finished workgroup
+#ifdef LKG_WS_STAMPS
+    if (EPI == EPI_PLAIN && g.z_out && (lt & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.z_out);
+        atomicAdd(dbg + 8, t_bar); atomicAdd(dbg + 9, t_issue); atomicAdd(dbg + 10, t_mem); atomicAdd(dbg + 11, t_stage);
+        atomicAdd(dbg + 12, (unsigned long long)n_items);
+    }
+#endif
+#undef LKG_WS_WAIT_A
+#undef LKG_WS_ISSUE
+#undef LKG_WS_STAGE
+}
+
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_tall_ws_kernel(TallArgs g) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // ---- this workgroup's row tiles: workgroup b lives on XCD b & 7 and walks every (gridDim.x / 8)-th row tile of that
+    // XCD's contiguous range (the same stripe as the forms above, over ROW tiles)
+    const int cpx = g.tiles_m >> 3, rem = g.tiles_m & 7, xcd = blockIdx.x & 7;
+    const int xcd_first = xcd * cpx + min(xcd, rem), xcd_count = cpx + (xcd < rem ? 1 : 0);
+    const int slot_stride = max(1, (int)gridDim.x >> 3), slot0 = blockIdx.x >> 3;
+    if (slot0 >= xcd_count) return;                                    // (workgroup-uniform)
+    const int n_rt = (xcd_count - slot0 + slot_stride - 1) / slot_stride;
+    const int kt_total = g.ktiles_total;
+    const int n_items = n_rt * g.tiles_n * kt_total;
+    const WsShape shp{n_rt, g.tiles_n, kt_total, g.ktiles[0], g.ktiles[1], g.ktiles[2]};
+    auto advance = [&](WsWalk &w) __attribute__((always_inline)) { ws_advance(w, shp); };
+    auto row0_of = [&](int rt) __attribute__((always_inline)) { return (long)(xcd_first + slot0 + rt * slot_stride) * TM; };
+#define LKG_WS_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+    if (wave >= 4) {
+        ws_loader<EPI>(g, lds, t - 256, wave - 4, n_rt, n_items, xcd_first + slot0, slot_stride);
+        return;
+    }
+
+    // =========================================================================================== compute: B stream + MFMA
+    const int wm_k = wave >> 1, wn_k = wave & 1;                      // (the k loop's copies; the epilogue re-derives its own)
+    typedef __attribute__((address_space(1))) const uint4 gu4;
+    WsWalk bw{0, 0, 0, 0, 0}, cw{0, 0, 0, 0, 0};
+    // item bw: 16 KB of ready-made planes, 4 requests per wave -- issued one by one between the step's MFMAs (a request
+    // holds the wave's issue port for ~60-100 cycles: four in a row in front of the MFMAs would idle the matrix pipe)
+    const uint4 *b_src = nullptr;
+    uint4 *b_dst = nullptr;
+    auto plan_b = [&](int buf) __attribute__((always_inline)) {
+        b_src = reinterpret_cast<const uint4 *>(g.bp) + ((long)bw.tn * kt_total + bw.gt) * (2 * WS_BPL / 8) + t;
+        b_dst = reinterpret_cast<uint4 *>(lds + WS_OFF_B + buf * (2 * WS_BPL * 2)) + wave * 64;
+        advance(bw);
+    };
+    auto issue_b_piece = [&](int q) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((gu4 *)(b_src + q * 256), (lds_void *)(b_dst + q * 256), 16, 0, 0);
+    };
+    auto issue_b = [&](int buf) __attribute__((always_inline)) {
+        plan_b(buf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_b_piece(q);
+    };
+    f32x16 acc[2][4];
+    // The epilogue's coordinates, re-derived per tile from an OPAQUE copy of threadIdx.x: everything computed from them --
+    // LDS addresses of 32 rows, column indices, the transposes' addresses -- is then per-tile work that hipcc cannot hoist
+    // out of the persistent loop, where it would sit in registers (and spill: 102 VGPRs with the LayerNorm epilogue) across
+    // a k loop that has none to spare.
+    int lane_e = lane, wm = wm_k, wn = wn_k;
+    float *ts = reinterpret_cast<float *>(lds + WS_OFF_TS) + wave * 1024;
+    auto rethread = [&]() __attribute__((always_inline)) {
+        int t_o = threadIdx.x;
+        asm volatile("" : "+v"(t_o));
+        lane_e = t_o & 63;
+        wm = (t_o >> 6) >> 1;
+        wn = (t_o >> 6) & 1;
+        ts = reinterpret_cast<float *>(lds + WS_OFF_TS) + (t_o >> 6) * 1024;
+    };
+    // one 32 x 32 block through the wave's private 4 KB: every lane then stores 16 bytes, 8 rows x 128 B per instruction
+    auto put = [&](const float(&v)[16]) {
+        const int lane = lane_e;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ts[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v[r];
+    };
+    auto flush = [&](float *base, long ld, long row0, int col0, int n_cols, float beta) __attribute__((always_inline)) {
+        const int lane = lane_e;
+        const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        const int col = col0 + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long row = row0 + 8 * q + (lane >> 3);
+            float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+            if (row >= g.m) continue;
+            float *dst = base + row * ld + col;
+            if (vec && col + 3 < n_cols) {
+                if (beta != 0.f) {
+                    const float4 o = *reinterpret_cast<const float4 *>(dst);
+                    v.x = fmaf(beta, o.x, v.x); v.y = fmaf(beta, o.y, v.y); v.z = fmaf(beta, o.z, v.z); v.w = fmaf(beta, o.w, v.w);
+                }
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                const nt4 nv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(dst));
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (col + k < n_cols) dst[k] = beta != 0.f ? fmaf(beta, dst[k], e[k]) : e[k];
+            }
+        }
+    };
+    if constexpr (EPI == EPI_ACTLN) {
+        // one column tile: the per-column scalars are the same for every tile -- into LDS once (visible behind barrier 0),
+        // read in the epilogue where they are needed instead of riding in 16 registers through the tile's last k step
+        float *cs = reinterpret_cast<float *>(lds + WS_OFF_COL);
+        const int c_ = min(t, g.n - 1);
+        reinterpret_cast<int *>(cs)[t] = g.eb[t];
+        cs[256 + t] = g.bias ? g.bias[c_] : 0.f;
+        cs[512 + t] = g.gamma[c_];
+        cs[768 + t] = g.beta_ln[c_];
+    }
+    issue_b(0);
+    issue_b(1);
+    int abuf = 0, bbuf = 0, bnext = 2;
+    bool stores_pending = false;
+#ifdef LKG_WS_STAMPS
+    unsigned long long t_mem = 0, t_bar = 0, t_step = 0, t_epi = 0;
+#endif
+    // The accumulators are never zeroed: a tile's first eight MFMAs take the constant 0 as their C operand.  (Zeroed under
+    // "first k tile" at the loop head, the old accumulators stay live through the epilogue on the path hipcc cannot rule out --
+    // and an epilogue that rewrites them, the LayerNorm one, spilled 100 VGPRs.)
+    for (int it = 0; it < n_items; ++it) {
+        LKG_STAMP(c0);
+        // this wave's pieces of B(it) are in: everything but the 4 requests of B(it + 1) -- after an epilogue only vmcnt(0)
+        // says so (its stores are younger and retire out of order with the loads)
+        if (stores_pending) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        stores_pending = false;
+        LKG_STAMP(c1);
+        LKG_WS_BARRIER();                                              // ---- barrier `it`
+        LKG_STAMP(c2);
+        const bool last_k = cw.gt == kt_total - 1;                     // (wave-uniform)
+        // the epilogue's per-column scalars: requested under the tile's last 24 MFMAs
+        const int n0 = cw.tn * 256;
+        int eb_v[4];
+        float bias_v[4];
+        if (last_k) rethread();
+        if (last_k && EPI != EPI_ACTLN) {
+            const int lane = lane_e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sc = n0 + wn * 128 + j * 32 + (lane & 31);   // stacked column of the tile
+                eb_v[j] = g.eb[sc];
+                if constexpr (EPI == EPI_GATE) {     // stacked column s of the tile: group (s / 32) & 1, output column (s / 64) * 32 + s % 32
+                    const int s_ = sc - n0, d = g.n / 2, oc = min((n0 >> 1) + (s_ >> 6) * 32 + (s_ & 31), d - 1);
+                    bias_v[j] = g.bias ? g.bias[((s_ >> 5) & 1) * d + oc] : 0.f;
+                } else {
+                    bias_v[j] = g.bias ? g.bias[min(sc, g.n - 1)] : 0.f;
+                }
+            }
+        }
+        plan_b(bnext);                                                 // item it + 2 into the buffer B(it - 1) left: requested below
+        {
+            const _Float16 *Ap = reinterpret_cast<const _Float16 *>(lds + WS_OFF_A) + abuf * (2 * WS_APL);
+            const _Float16 *Bp = reinterpret_cast<const _Float16 *>(lds + WS_OFF_B) + bbuf * (2 * WS_BPL);
+            auto fa = [&](int i, int pl) __attribute__((always_inline)) { return frag<256>(Ap + pl * WS_APL, wm_k * 64 + i * 32, lane); };
+            auto fb = [&](int j, int pl) __attribute__((always_inline)) { return frag<256>(Bp + pl * WS_BPL, wn_k * 128 + j * 32, lane); };
+#define LKG_MFMA(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
+#define LKG_MFMA0(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, zero16, 0, 0, 0)
+#define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f16x8 ah[2], am[2], bh[4], bm[4];
+            ah[0] = fa(0, 0); bh[0] = fb(0, 0); bh[1] = fb(1, 0); bh[2] = fb(2, 0); bh[3] = fb(3, 0); ah[1] = fa(1, 0);
+            LKG_PIN();
+            if (cw.gt == 0) {                                           // (wave-uniform) a tile's first step: C = 0
+                LKG_MFMA0(acc[0][0], ah[0], bh[0]); am[0] = fa(0, 1); LKG_PIN();
+                LKG_MFMA0(acc[0][1], ah[0], bh[1]); am[1] = fa(1, 1); LKG_PIN();
+                LKG_MFMA0(acc[0][2], ah[0], bh[2]); LKG_PIN();
+                LKG_MFMA0(acc[0][3], ah[0], bh[3]); LKG_PIN();
+                LKG_MFMA0(acc[1][0], ah[1], bh[0]); LKG_PIN();
+                LKG_MFMA0(acc[1][1], ah[1], bh[1]); LKG_PIN();
+                LKG_MFMA0(acc[1][2], ah[1], bh[2]); LKG_PIN();
+                LKG_MFMA0(acc[1][3], ah[1], bh[3]); LKG_PIN();
+            } else {
+                LKG_MFMA(acc[0][0], ah[0], bh[0]); am[0] = fa(0, 1); LKG_PIN();
+                LKG_MFMA(acc[0][1], ah[0], bh[1]); am[1] = fa(1, 1); LKG_PIN();
+                LKG_MFMA(acc[0][2], ah[0], bh[2]); LKG_PIN();
+                LKG_MFMA(acc[0][3], ah[0], bh[3]); LKG_PIN();
+                LKG_MFMA(acc[1][0], ah[1], bh[0]); LKG_PIN();
+                LKG_MFMA(acc[1][1], ah[1], bh[1]); LKG_PIN();
+                LKG_MFMA(acc[1][2], ah[1], bh[2]); LKG_PIN();
+                LKG_MFMA(acc[1][3], ah[1], bh[3]); LKG_PIN();
+            }
+            LKG_MFMA(acc[0][0], am[0], bh[0]); bm[0] = fb(0, 1); LKG_PIN();
+            LKG_MFMA(acc[0][1], am[0], bh[1]); bm[1] = fb(1, 1); LKG_PIN();
+            LKG_MFMA(acc[0][2], am[0], bh[2]); issue_b_piece(0); LKG_PIN();
+            LKG_MFMA(acc[0][3], am[0], bh[3]); LKG_PIN();
+            LKG_MFMA(acc[1][0], am[1], bh[0]); bm[2] = fb(2, 1); LKG_PIN();
+            LKG_MFMA(acc[1][1], am[1], bh[1]); bm[3] = fb(3, 1); LKG_PIN();
+            LKG_MFMA(acc[1][2], am[1], bh[2]); issue_b_piece(1); LKG_PIN();
+            LKG_MFMA(acc[1][3], am[1], bh[3]); LKG_PIN();
+            LKG_MFMA(acc[0][0], ah[0], bm[0]); LKG_PIN();
+            LKG_MFMA(acc[1][0], ah[1], bm[0]); issue_b_piece(2); LKG_PIN();
+            LKG_MFMA(acc[0][1], ah[0], bm[1]); LKG_PIN();
+            LKG_MFMA(acc[1][1], ah[1], bm[1]); LKG_PIN();
+            LKG_MFMA(acc[0][2], ah[0], bm[2]); issue_b_piece(3); LKG_PIN();
+            LKG_MFMA(acc[1][2], ah[1], bm[2]); LKG_PIN();
+            LKG_MFMA(acc[0][3], ah[0], bm[3]); LKG_PIN();
+            LKG_MFMA(acc[1][3], ah[1], bm[3]);
+#undef LKG_MFMA
+#undef LKG_MFMA0
+#undef LKG_PIN
+        }
+        abuf ^= 1;
+        bbuf = bbuf == WS_NB - 1 ? 0 : bbuf + 1;
+        bnext = bnext == WS_NB - 1 ? 0 : bnext + 1;
+#ifdef LKG_WS_STAMPS
+        asm volatile("s_nop 0" :: "v"(acc[1][3][0]));                  // (the step's last MFMA has issued)
+#endif
+        LKG_STAMP(c3);
+        LKG_STAMP_ADD(t_mem, c0, c1); LKG_STAMP_ADD(t_bar, c1, c2); LKG_STAMP_ADD(t_step, c2, c3);
+        if (last_k) {
+            // ------------------------------------------------------------------------------------------------ epilogue
+            const int lane = lane_e;                                   // (the opaque copy: see rethread())
+            const long m0 = row0_of(cw.rt);
+            const int *ea_s = reinterpret_cast<const int *>(lds + WS_OFF_EA) + ((cw.rt * g.tiles_n + cw.tn) & 1) * TM;
+            if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col0 = n0 + wn * 128 + j * 32;
+                        if (col0 >= g.n) continue;                                // wave-uniform
+                        const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
+                        float out[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            out[r] = g.alpha * ldexpf(acc[i][j][r], -(ea_s[lr0 + (r & 3) + 8 * (r >> 2)] + eb_v[j])) + bias_v[j];
+                        put(out);
+                        flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else if constexpr (EPI == EPI_GATE) {
+                // of every pair of tile column blocks, block 2 pr holds g and block 2 pr + 1 holds z of the SAME output columns
+                const int d = g.n / 2;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int col0 = (n0 >> 1) + wn * 64 + pr * 32;
+                    if (col0 >= d) continue;                                      // wave-uniform
+                    const int cc = min(col0 + (lane & 31), d - 1);                // lanes past d compute on a clamped column, never stored
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);
+                        const long row0 = m0 + wm * 64 + i * 32;
+                        float xv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)                              // x[rows of the block, this lane's output column]
+                            xv[r] = g.x[min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1) * g.ldx + cc];
+                        float ov[16], gv[16], zv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int e = ea_s[lr0 + (r & 3) + 8 * (r >> 2)];
+                            const float gp = ldexpf(acc[i][2 * pr][r], -(e + eb_v[2 * pr])) + bias_v[2 * pr];
+                            const float zp = ldexpf(acc[i][2 * pr + 1][r], -(e + eb_v[2 * pr + 1])) + bias_v[2 * pr + 1];
+                            gv[r] = tanh_fast(gp);
+                            zv[r] = sigmoid_fast(zp);
+                            ov[r] = fmaf(zv[r], gv[r] - xv[r], xv[r]);            // (1 - z) x + z g
+                        }
+                        put(ov);
+                        flush(g.c, g.ldc, row0, col0, d, 0.f);
+                        if (g.g_out) {
+                            put(gv);
+                            flush(g.g_out, g.ldg, row0, col0, d, 0.f);
+                        }
+                        if (g.z_out) {
+                            put(zv);
+                            flush(g.z_out, g.ldz, row0, col0, d, 0.f);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+                // LeakyReLU -> LayerNorm -> dropout (+ the L2-normalised copy): the tile holds whole rows (n <= 256), a row's
+                // 256 columns live in the two waves wn = 0 / 1 of a row half -- three sums per row cross them through LDS
+                float *st = reinterpret_cast<float *>(lds + WS_OFF_ST);            // [3][2][TM]
+                const float *cs = reinterpret_cast<const float *>(lds + WS_OFF_COL);
+                float gam_v[4], bet_v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sc = wn * 128 + j * 32 + (lane & 31);
+                    eb_v[j] = reinterpret_cast<const int *>(cs)[sc];
+                    bias_v[j] = cs[256 + sc];
+                    gam_v[j] = cs[512 + sc];
+                    bet_v[j] = cs[768 + sc];
+                }
+                const float inv_n = 1.f / (float)g.n;
+                auto row_of = [&](int i, int r) __attribute__((always_inline)) { return wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); };
+                // a row's partial sum over this wave's 128 columns -> LDS (one lane per row writes); after the barrier either
+                // wave reads both halves back where it needs the total (nothing per-row lives in registers between the passes)
+                auto share = [&](float v, int which, int i, int r) __attribute__((always_inline)) {
+                    v = group_sum<32>(v);
+                    if ((lane & 31) == r) st[(which * 2 + wn) * TM + row_of(i, r)] = v;
+                };
+                auto total = [&](int which, int i, int r) __attribute__((always_inline)) {
+                    return st[(which * 2) * TM + row_of(i, r)] + st[(which * 2 + 1) * TM + row_of(i, r)];
+                };
+                auto sync = [&]() __attribute__((always_inline)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    LKG_WS_BARRIER();
+                };
+                // One ROW HALF of the wave's tile at a time (i = 0, 1: 32 rows x 128 columns, four accumulators): all three sums,
+                // then the stores -- the rewritten values of one half live beside the untouched accumulators of the other, not
+                // beside a second copy of all eight (which spilled 100 VGPRs).  Six barriers per tile; the loaders match them.
+                const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+                auto half = [&](auto I) __attribute__((always_inline)) {            // (a generic lambda called with 0 and 1: `i` stays a constant -- the body is too
+                    constexpr int i = decltype(I)::value;   //  large for hipcc to unroll as a loop, and a runtime i indexes scratch)
+                    float row_a[16], row_b[16];                                    // per-row values of the half (sums, then mean / rstd)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) row_a[r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool live = wn * 128 + j * 32 + (lane & 31) < g.n;
+                        f32x16 blk = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int e = ea_s[wm * 64 + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2)];
+                            float v = ldexpf(blk[r], -(e + eb_v[j])) + bias_v[j];
+                            v = v > 0.f ? v : v * g.slope;
+                            v = live ? v : 0.f;
+                            blk[r] = v;
+                            row_a[r] += v;
+                        }
+                        acc[i][j] = blk;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) share(row_a[r], 0, i, r);
+                    sync();                                                        // row sums -> means
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        row_a[r] = total(0, i, r) * inv_n;
+                        row_b[r] = 0.f;
+                        const long grow = m0 + row_of(i, r);
+                        if (wn == 0 && (lane & 31) == r && grow < g.m) g.mean[grow] = row_a[r];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                      // the CENTRED values go back into the accumulators: the means
+                        const bool live = wn * 128 + j * 32 + (lane & 31) < g.n;       // are not needed (in registers) after this pass
+                        f32x16 blk = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float c = live ? blk[r] - row_a[r] : 0.f;
+                            blk[r] = c;
+                            row_b[r] = fmaf(c, c, row_b[r]);
+                        }
+                        acc[i][j] = blk;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) share(row_b[r], 1, i, r);
+                    sync();                                                        // centred squares -> 1 / std
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        row_b[r] = 1.f / sqrtf(total(1, i, r) * inv_n + g.ln_eps);
+                        const long grow = m0 + row_of(i, r);
+                        if (wn == 0 && (lane & 31) == r && grow < g.m) g.rstd[grow] = row_b[r];
+                        row_a[r] = 0.f;                                 // (from here on: the row's sum of squares of y)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = wn * 128 + j * 32 + (lane & 31);
+                        f32x16 blk = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float o = blk[r] * row_b[r] * gam_v[j] + bet_v[j];
+                            if (g.drop_p > 0.f)       // (the row key is recomputed per element: 16 keys would not fit beside the rest)
+                                o *= drop_scale(drop_row_key(g.seed, (unsigned long long)(m0 + row_of(i, r))), (unsigned)col, g.drop_p, inv_keep);
+                            o = col < g.n ? o : 0.f;
+                            blk[r] = o;
+                            row_a[r] = fmaf(o, o, row_a[r]);
+                        }
+                        acc[i][j] = blk;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) share(row_a[r], 2, i, r);
+                    sync();                                                        // |y|^2 -> the normalised copy's scale
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col0 = wn * 128 + j * 32;
+                        if (col0 >= g.n) continue;                                // wave-uniform
+                        float out[16];
+                        if (g.c) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) out[r] = acc[i][j][r];
+                            put(out);
+                            flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, 0.f);
+                        }
+                        if (g.yn) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) out[r] = acc[i][j][r] * (1.f / fmaxf(sqrtf(total(2, i, r)), g.norm_eps));
+                            put(out);
+                            flush(g.yn, g.ldyn, m0 + wm * 64 + i * 32, col0, g.n, 0.f);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                half(std::integral_constant<int, 0>{});
+                half(std::integral_constant<int, 1>{});
+            }
+            stores_pending = true;
+            LKG_STAMP(c4);
+            LKG_STAMP_ADD(t_epi, c3, c4);
+        }
+        advance(cw);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef LKG_WS_STAMPS
+    if (EPI == EPI_PLAIN && g.z_out && lane == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.z_out);
+        atomicAdd(dbg + 0, t_mem); atomicAdd(dbg + 1, t_bar); atomicAdd(dbg + 2, t_step); atomicAdd(dbg + 3, t_epi);
+        atomicAdd(dbg + 4, (unsigned long long)n_items);
+    }
+#endif
+#undef LKG_WS_BARRIER
+}
+
 // out[i] = max_j |x[i, j]|   (accumulate: max with the value already there).  One wave per row.
 __global__ __launch_bounds__(256) void row_absmax_kernel(long n, int d, const float *__restrict__ x, long ldx,
                                                          float *__restrict__ out, int accumulate, int vec) {
@@ -832,7 +1485,9 @@ inline int total_ktiles(int n_panels, const int32_t *ka) {
 // tile width and number of column tiles: the gate's stacked columns are interleaved in blocks of 32 (g, z, g, z ...), so
 // its stacked extent is 64 per 32 output columns
 // variant: 0 "256x2" (two accumulators, 128 x 256 tiles), 1 "128x1", 2 "256x1" (one accumulator, 8 waves of 64 x 64),
-// 3 "256x1w" (one accumulator, prescaled mids, 4 waves of 64 x 128).  Chosen PER CALL: bits 8-15 of the `epilogue`
+// 3 "256x1w" (one accumulator, prescaled mids, 4 waves of 64 x 128), 4 "ws" (wave-specialised: one 8-wave workgroup per CU,
+// loader waves for the A stream, compute waves of 64 x 128 for B + MFMA; the only form of the act + LayerNorm epilogue;
+// outputs of at most 128 columns without that epilogue stay on "128x1").  Chosen PER CALL: bits 8-15 of the `epilogue`
 // argument hold variant + 1 (0 = the library's default), so a test or a tool runs any variant next to any other in one
 // process and nothing in the environment selects code (LKG_TALL_VARIANT is gone).
 inline int variant_of(int epilogue_arg) {
@@ -845,10 +1500,19 @@ inline void geometry(int n, int epilogue_arg, int &bn, int &tiles_n) {
         bn = v == 1 ? 128 : 256;
         tiles_n = ((n / 2 + 31) / 32 * 64 + bn - 1) / bn;
     } else {
-        bn = (n <= 128 || v == 1) ? 128 : 256;
+        bn = ((n <= 128 && epilogue != EPI_ACTLN) || v == 1) ? 128 : 256;
         tiles_n = (n + bn - 1) / bn;
     }
 }
+
+struct LnExtra {             // the act + LayerNorm epilogue's operands (lkg_linear_act_layernorm_fwd_f32)
+    float slope, ln_eps, norm_eps, drop_p;
+    unsigned long long seed;
+    const float *gamma, *beta;
+    float *yn;
+    int64_t ldyn;
+    float *mean, *rstd;
+};
 
 }  // namespace
 
@@ -871,28 +1535,33 @@ extern "C" int64_t lkg_gemm_tall_workspace(int32_t n, int32_t n_panels, const in
     return (long)tiles_n * total_ktiles(n_panels, ka) * (2L * bn * TK) * 2 + (long)tiles_n * bn * 4 + 256;
 }
 
-extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
-                                 const int32_t *ka, const float *a_rowmax, int32_t n_groups, const float *const *b,
-                                 const int64_t *ldb, int32_t trans_b, float alpha, float beta, float *c, int64_t ldc,
-                                 const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
-                                 int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
-                                 void *stream) {
+static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
+                     const int32_t *ka, const float *a_rowmax, int32_t n_groups, const float *const *b,
+                     const int64_t *ldb, int32_t trans_b, float alpha, float beta, float *c, int64_t ldc,
+                     const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
+                     int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
+                     void *stream, const LnExtra *ln) {
     const int32_t epilogue_arg = epilogue;          // bits 0-7: the epilogue, bits 8-15: variant + 1 (0 = default)
     epilogue = epilogue_arg & 0xff;
-    LKG_REQUIRE((epilogue_arg >> 16) == 0 && ((epilogue_arg >> 8) & 0xff) <= 4, "lkg_gemm_tall_f32: unknown variant in the "
+    LKG_REQUIRE((epilogue_arg >> 16) == 0 && ((epilogue_arg >> 8) & 0xff) <= 5, "lkg_gemm_tall_f32: unknown variant in the "
                 "epilogue argument (0x%x)", epilogue_arg);
     LKG_REQUIRE(m >= 0 && n > 0 && n_panels >= 1 && n_panels <= MAX_PANELS, "lkg_gemm_tall_f32: bad sizes");
-    LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE, "lkg_gemm_tall_f32: unknown epilogue %d", epilogue);
+    LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE || (epilogue == EPI_ACTLN && ln),
+                "lkg_gemm_tall_f32: unknown epilogue %d", epilogue);
+    LKG_REQUIRE(epilogue != EPI_ACTLN || (n <= 256 && alpha == 1.f && beta == 0.f && ln->gamma && ln->beta && ln->mean &&
+                                          ln->rstd && (c || ln->yn) && (!ln->yn || ln->ldyn >= n) && ln->drop_p >= 0.f &&
+                                          ln->drop_p < 1.f),
+                "lkg_linear_act_layernorm_fwd_f32: at most 256 output columns, gamma / beta / mean / rstd, an output, 0 <= p < 1");
     LKG_REQUIRE(n_groups == (epilogue == EPI_GATE ? 2 : 1), "lkg_gemm_tall_f32: the gate stacks 2 weight groups, a plain "
                 "product 1");
     if (m == 0) return LKG_OK;
-    LKG_REQUIRE(a && lda && ka && a_rowmax && b && ldb && c && workspace, "lkg_gemm_tall_f32: null pointer");
+    LKG_REQUIRE(a && lda && ka && a_rowmax && b && ldb && (c || epilogue == EPI_ACTLN) && workspace, "lkg_gemm_tall_f32: null pointer");
     const int d_out = epilogue == EPI_GATE ? n / 2 : n;
     LKG_REQUIRE(epilogue != EPI_GATE || (n % 2 == 0 && gate_x && ld_x >= d_out && beta == 0.f && alpha == 1.f),
                 "lkg_gemm_tall_f32: gate epilogue needs x, an even stacked width, alpha = 1, beta = 0");
     LKG_REQUIRE(epilogue != EPI_GATE || (gate_x == a[0] && ld_x == lda[0] && ka[0] == d_out),
                 "lkg_gemm_tall_f32: the gate blends its FIRST K-panel (gate_x must be a[0], %d wide)", d_out);
-    LKG_REQUIRE(ldc >= d_out, "lkg_gemm_tall_f32: ldc %lld smaller than the output width %d", (long long)ldc, d_out);
+    LKG_REQUIRE(!c || ldc >= d_out, "lkg_gemm_tall_f32: ldc %lld smaller than the output width %d", (long long)ldc, d_out);
     const int64_t need = lkg_gemm_tall_workspace(n, n_panels, ka, epilogue_arg);
     LKG_REQUIRE(workspace_bytes >= need, "lkg_gemm_tall_f32: workspace of %lld bytes is smaller than the %lld required",
                 (long long)workspace_bytes, (long long)need);
@@ -900,7 +1569,8 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
     int bn, tiles_n;
     geometry(n, epilogue_arg, bn, tiles_n);
     const int variant = variant_of(epilogue_arg);
-    const bool wide = variant == 3 && bn == 256;     // 4 waves of 64 x 128, prescaled mids
+    const bool ws = (variant == 4 || epilogue == EPI_ACTLN) && bn == 256;     // wave-specialised (the fused layer epilogue: always)
+    const bool wide = (variant == 3 && bn == 256) || ws;                      // prescaled mid planes
     TallArgs g{};
     BDesc bd{};
     g.m = m; g.n = n; g.n_panels = n_panels;
@@ -974,7 +1644,37 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
         const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
         hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_, WN_>), grid, dim3(2 * (BN_ / WN_) * 64), lds, s, g);     \
     } while (0)
-    if (wide) {
+    if (ws) {
+        if (ln) {
+            g.slope = ln->slope; g.ln_eps = ln->ln_eps; g.norm_eps = ln->norm_eps; g.drop_p = ln->drop_p; g.seed = ln->seed;
+            g.gamma = ln->gamma; g.beta_ln = ln->beta; g.yn = ln->yn; g.ldyn = ln->ldyn; g.mean = ln->mean; g.rstd = ln->rstd;
+        }
+#define LKG_TALL_GO_WS(EPI_)                                                                                           \
+    do {                                                                                                               \
+        static bool raised = false;                                                                                    \
+        static int cus = 0;                                                                                            \
+        if (!raised) {                                                                                                 \
+            int dev_ = 0, per_cu_ = 0;                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_ws_kernel<EPI_>),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess ||         \
+                hipGetDevice(&dev_) != hipSuccess ||                                                                   \
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess ||              \
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_ws_kernel<EPI_>, 512, WS_LDS_BYTES)   \
+                    != hipSuccess || per_cu_ < 1 || cus < 8) {                                                         \
+                lkg_set_error("lkg_gemm_tall_f32: cannot set up the wave-specialised kernel (LDS limit / occupancy)"); \
+                return LKG_ERR_HIP;                                                                                    \
+            }                                                                                                          \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        /* persistent: one workgroup per CU (a multiple of 8: one stripe of row tiles per workgroup and XCD) */         \
+        const dim3 grid((unsigned)std::min<long>(((long)g.tiles_m + 7) / 8 * 8, (long)(cus / 8 * 8)));                 \
+        hipLaunchKernelGGL((gemm_tall_ws_kernel<EPI_>), grid, dim3(512), WS_LDS_BYTES, s, g);                          \
+    } while (0)
+        if (epilogue == EPI_GATE) LKG_TALL_GO_WS(EPI_GATE);
+        else if (epilogue == EPI_ACTLN) LKG_TALL_GO_WS(EPI_ACTLN);
+        else LKG_TALL_GO_WS(EPI_PLAIN);
+#undef LKG_TALL_GO_WS
+    } else if (wide) {
         if (epilogue == EPI_GATE) LKG_TALL_GO_W(256, EPI_GATE, true, 128);
         else LKG_TALL_GO_W(256, EPI_PLAIN, true, 128);
     } else if (epilogue == EPI_GATE) {
@@ -992,6 +1692,34 @@ extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const f
 #undef LKG_TALL_GO_W
     LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
     return LKG_OK;
+}
+
+extern "C" int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a, const int64_t *lda,
+                                 const int32_t *ka, const float *a_rowmax, int32_t n_groups, const float *const *b,
+                                 const int64_t *ldb, int32_t trans_b, float alpha, float beta, float *c, int64_t ldc,
+                                 const float *bias, int32_t epilogue, const float *gate_x, int64_t ld_x, float *gate_g,
+                                 int64_t ld_g, float *gate_z, int64_t ld_z, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    LKG_REQUIRE((epilogue & 0xff) != EPI_ACTLN, "lkg_gemm_tall_f32: the act + LayerNorm epilogue has its own entry point "
+                "(lkg_linear_act_layernorm_fwd_f32)");
+    return tall_call(m, n, n_panels, a, lda, ka, a_rowmax, n_groups, b, ldb, trans_b, alpha, beta, c, ldc, bias, epilogue,
+                     gate_x, ld_x, gate_g, ld_g, gate_z, ld_z, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int64_t lkg_linear_act_layernorm_workspace(int32_t n, int32_t n_panels, const int32_t *ka) {
+    return lkg_gemm_tall_workspace(n, n_panels, ka, EPI_ACTLN);
+}
+
+extern "C" int lkg_linear_act_layernorm_fwd_f32(int64_t m, int32_t n, int32_t n_panels, const float *const *a,
+                                                const int64_t *lda, const int32_t *ka, const float *a_rowmax,
+                                                const float *const *w, const int64_t *ldw, const float *bias, float slope,
+                                                const float *gamma, const float *beta, float eps, float *y, int64_t ldy,
+                                                float *yn, int64_t ldyn, float norm_eps, float *save_mean,
+                                                float *save_rstd, float drop_p, uint64_t seed, void *workspace,
+                                                int64_t workspace_bytes, void *stream) {
+    const LnExtra ln{slope, eps, norm_eps, drop_p, (unsigned long long)seed, gamma, beta, yn, ldyn, save_mean, save_rstd};
+    return tall_call(m, n, n_panels, a, lda, ka, a_rowmax, 1, w, ldw, 1, 1.f, 0.f, y, ldy, bias, EPI_ACTLN, nullptr, 0,
+                     nullptr, 0, nullptr, 0, workspace, workspace_bytes, stream, &ln);
 }
 
 // lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's

@@ -48,24 +48,8 @@ struct RowRegs {
     __device__ __forceinline__ bool live(int k, int d, int lane) const { return (lane + 64 * (k / W)) * W + (k % W) < d; }
 };
 
-// Counter-based dropout mask: keep(seed, row, col) is a pure function (two rounds of the murmur3 32-bit
-// finaliser), so the backward regenerates the mask instead of storing it.  torch's Philox stream cannot be
-// reproduced from outside ATen, so training-mode parity with the reference is statistical.
-__device__ __forceinline__ unsigned fmix32(unsigned h) {
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    return h ^ (h >> 16);
-}
-__device__ __forceinline__ unsigned drop_row_key(unsigned long long seed, unsigned long long row) {
-    return fmix32((unsigned)seed ^ fmix32((unsigned)row * 0x9E3779B1u + (unsigned)(row >> 32) + (unsigned)(seed >> 32)));
-}
-__device__ __forceinline__ float drop_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
-    const unsigned h = fmix32(row_key ^ (col * 0x27D4EB2Fu + 0x165667B1u));
-    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
-}
-
+// (the counter-based dropout mask -- fmix32 / drop_row_key / drop_scale -- lives in lkg_common.h: the fused layer epilogue of
+// lkg_gemm_tall.hip draws the same mask)
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void act_ln_fwd_kernel(long n, int d, const float *__restrict__ z, long ldz,
                                                           float slope, const float *__restrict__ gamma,

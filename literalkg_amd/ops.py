@@ -581,7 +581,7 @@ def tall_ok(m: int, n: int, ks: Sequence[int], single_panel_too: bool = False) -
     return n * sum(ks) <= (1 << 22)
 
 
-TALL_VARIANTS = {"256x2": 0, "128x1": 1, "256x1": 2, "256x1w": 3}      # lkg_gemm_tall_f32: bits 8-15 of `epilogue` = id + 1
+TALL_VARIANTS = {"256x2": 0, "128x1": 1, "256x1": 2, "256x1w": 3, "ws": 4}      # lkg_gemm_tall_f32: bits 8-15 of `epilogue` = id + 1
 DEFAULT_TALL_VARIANT: Optional[str] = None      # None = the library's default; tests / tools set a key to steer whole modules
 
 
@@ -645,6 +645,55 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
            N.ptr(g_out), _ld(g_out) if g_out is not None else 0, N.ptr(z_out), _ld(z_out) if z_out is not None else 0,
            N.ptr(ws), ws.numel(), _stream())
     return out
+
+
+def fused_layer_ok(m: int, n: int, ks: Sequence[int]) -> bool:
+    """Can lkg_linear_act_layernorm_fwd_f32 take this Linear + LeakyReLU + LayerNorm?  (whole rows in one 256-column tile)"""
+    return (_ENGINE in ("f16x2", "f16x2-all") and m >= TALL_MIN_ROWS and 1 <= len(ks) <= 3 and min(ks) > 0 and 1 <= n <= 256
+            and n * sum(ks) <= (1 << 22))
+
+
+def linear_act_layernorm_fwd(a_panels: Sequence[torch.Tensor], w_blocks: Sequence[torch.Tensor], bias: Optional[torch.Tensor],
+                             gamma: torch.Tensor, beta: torch.Tensor, slope: float, eps: float, norm_eps: float,
+                             drop_p: float, seed: int, want_y: bool = True, want_norm: bool = True,
+                             yn_out: Optional[torch.Tensor] = None, rowmax: Optional[torch.Tensor] = None):
+    """(y, yn, mean, rstd) of  Dropout(LayerNorm(LeakyReLU(sum_p a_p @ w_p^T + bias)))  in ONE launch (K5 as surveyed:
+    lkg_linear_act_layernorm_fwd_f32); no autograd here -- ``linear_act_layernorm`` wraps it."""
+    if rowmax is None:
+        rowmax = rows_absmax(a_panels)
+    a_panels = [_f32_rows(a) for a in a_panels]
+    ws_ = [_f32_rows(w) for w in w_blocks]
+    _need_gpu(*a_panels, *ws_, gamma, beta)
+    m, n = a_panels[0].shape[0], ws_[0].shape[0]
+    ks = [a.shape[1] for a in a_panels]
+    if any(a.shape[0] != m for a in a_panels) or any(tuple(w.shape) != (n, k) for w, k in zip(ws_, ks)) or len(ws_) != len(ks):
+        raise ValueError("linear_act_layernorm: panels / weight blocks do not match")
+    if not (want_y or want_norm):
+        raise ValueError("linear_act_layernorm: neither output wanted")
+    if rowmax.numel() != m or gamma.numel() != n or beta.numel() != n or (bias is not None and bias.numel() != n):
+        raise ValueError("linear_act_layernorm: row maxima / gamma / beta / bias do not match the product's shape")
+    dev = a_panels[0].device
+    y = torch.empty((m, n), dtype=torch.float32, device=dev) if want_y else None
+    yn = None
+    if want_norm:
+        yn = yn_out if yn_out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
+        if tuple(yn.shape) != (m, n) or yn.stride(1) != 1 or yn.dtype != torch.float32:
+            raise ValueError("linear_act_layernorm: the normalised copy's destination must be an m x n float32 view with unit column stride")
+    mean = torch.empty(m, dtype=torch.float32, device=dev)
+    rstd = torch.empty(m, dtype=torch.float32, device=dev)
+    np_ = len(ks)
+    a_ptr = (_C.c_void_p * np_)(*[a.data_ptr() for a in a_panels])
+    a_ld = (_C.c_int64 * np_)(*[_ld(a) for a in a_panels])
+    a_k = (_C.c_int32 * np_)(*ks)
+    w_ptr = (_C.c_void_p * np_)(*[w.data_ptr() for w in ws_])
+    w_ld = (_C.c_int64 * np_)(*[_ld(w) for w in ws_])
+    need = N.load().lkg_linear_act_layernorm_workspace(n, np_, a_k)
+    ws = _workspace(int(need), dev)
+    N.call("lkg_linear_act_layernorm_fwd_f32", m, n, np_, a_ptr, a_ld, a_k, N.ptr(rowmax), w_ptr, w_ld, N.ptr(bias),
+           float(slope), N.ptr(gamma), N.ptr(beta), float(eps), N.ptr(y), _ld(y) if y is not None else 0, N.ptr(yn),
+           _ld(yn) if yn is not None else 0, float(norm_eps), N.ptr(mean), N.ptr(rstd), float(drop_p), int(seed), N.ptr(ws),
+           ws.numel(), _stream())
+    return y, yn, mean, rstd
 
 
 # ----------------------------------------------------------------------------- K1+K2 attention refresh

@@ -327,9 +327,9 @@ def test_gemm_tall_f16x2_engine_is_f32_accurate(ops, gpu_device, ks, n, tb):
     assert err4 <= max(10.0 * f32, 5e-6), (err4, f32)
 
 
-@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "128x1"])
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "128x1", "ws"])
 @pytest.mark.parametrize("ks,n,tb", [((256,), 256, True), ((256, 2, 300), 256, True), ((512,), 300, True), ((30, 7), 50, False),
-                                     ((40,), 200, True)])
+                                     ((40,), 200, True), ((16,), 600, True), ((3, 5, 2), 130, False)])
 def test_gemm_tall_every_tiling_variant_is_f32_accurate(ops, gpu_device, variant, ks, n, tb):
     """Every tiling of lkg_gemm_tall_f32 (bits 8-15 of its `epilogue` argument) against float64 on the same operands: the
     two-accumulator form, the 8-wave and the 4-wave (64 x 128 wave tiles, prescaled mids) one-accumulator forms and the
@@ -361,7 +361,7 @@ def test_gemm_tall_every_tiling_variant_is_f32_accurate(ops, gpu_device, variant
     assert float(got3[9].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w"])
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "ws"])
 def test_fused_gate_every_tiling_variant(L, ops, O, gpu_device, variant):
     """The gate's one-launch stacked product (blend epilogue) on every 256-column tiling against the oracle's gate."""
     torch.manual_seed(4)
@@ -378,6 +378,42 @@ def test_fused_gate_every_tiling_variant(L, ops, O, gpu_device, variant):
     finally:
         ops.DEFAULT_TALL_VARIANT = old
     torch.testing.assert_close(got.cpu(), want.float(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("m", [16384 + 5, 40_000])
+@pytest.mark.parametrize("ks,n", [((256,), 256), ((64, 64), 128), ((300,), 32), ((256, 2, 300), 200), ((40,), 7), ((128,), 256)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.25])
+def test_fused_layer_epilogue_matches_the_unfused_pair(ops, gpu_device, m, ks, n, drop_p):
+    """K5 in one launch (lkg_linear_act_layernorm_fwd_f32: Linear + LeakyReLU + LayerNorm + dropout + normalised copy in the
+    wave-specialised tall GEMM's epilogue) against the unfused pair lkg_gemm_tall_f32 + lkg_act_layernorm_fwd_f32 on the
+    same operands and the same dropout seed: y, yn, mean, rstd -- and against float64 LayerNorm of the float64 product."""
+    gen = torch.Generator().manual_seed(m + n + sum(ks))
+    panels = [torch.randn(m, k, generator=gen).to(gpu_device) * (0.5 + i) for i, k in enumerate(ks)]
+    ws = [(torch.randn(n, k, generator=gen) * 0.08).to(gpu_device) for k in ks]
+    bias = torch.randn(n, generator=gen).to(gpu_device) * 0.1
+    gamma = (1 + 0.1 * torch.randn(n, generator=gen)).to(gpu_device)
+    beta = (0.1 * torch.randn(n, generator=gen)).to(gpu_device)
+    seed = 1234567
+    slot = torch.zeros((m, n + 9), device=gpu_device)[:, 4:4 + n]                       # a strided destination, like a CatBuffer slot
+    y, yn, mean, rstd = ops.linear_act_layernorm_fwd(panels, ws, bias, gamma, beta, 0.01, 1e-5, 1e-12, drop_p, seed, yn_out=slot)
+    z = ops.gemm_tall(panels, (ws,), True, bias) if ops.tall_ok(m, n, ks, True) else \
+        sum(p @ w.t() for p, w in zip(panels, ws)) + bias
+    y0, yn0 = ops.act_layernorm(z, gamma, beta, want_norm=True, drop_p=drop_p, seed=seed)
+    kept = (y0 != 0) == (y != 0)
+    assert bool(kept.all()), "the two paths must draw the same dropout mask"
+    torch.testing.assert_close(y, y0, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(yn, yn0, rtol=2e-5, atol=2e-6)
+    assert yn.data_ptr() == slot.data_ptr()
+    z64 = sum(p.double() @ w.double().t() for p, w in zip(panels, ws)) + bias.double()
+    a64 = torch.where(z64 > 0, z64, 0.01 * z64)
+    mu, var = a64.mean(1, keepdim=True), a64.var(1, unbiased=False, keepdim=True)
+    torch.testing.assert_close(mean.double(), mu[:, 0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd.double(), (var[:, 0] + 1e-5).rsqrt(), rtol=2e-5, atol=1e-6)
+    if drop_p == 0.0:
+        want = (a64 - mu) / (var + 1e-5).sqrt() * gamma.double() + beta.double()
+        torch.testing.assert_close(y.double(), want, rtol=1e-4, atol=1e-4)     # (fp32 statistics over as few as 7 columns)
+        _, yn_only, _, _ = ops.linear_act_layernorm_fwd(panels, ws, bias, gamma, beta, 0.01, 1e-5, 1e-12, 0.0, 0, want_y=False)
+        torch.testing.assert_close(yn_only, yn, rtol=0, atol=0)
 
 
 def test_fused_gate_matches_oracle_and_the_unfused_path(L, ops, O, gpu_device):

@@ -24,7 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--n", type=int, default=1_000_000)
-ap.add_argument("--variants", default="256x1,256x1w,256x2")
+ap.add_argument("--variants", default="256x1,256x1w,ws")
 ap.add_argument("--json", default=None)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -94,5 +94,37 @@ for v in variants:
     med, mn = float(np.median(times[v])), float(np.min(times[v]))
     res[f"gate forward [{v}]"] = {"median_ms": med, "min_ms": mn, "tflops_f32_equivalent": fl / med / 1e9, "algorithmic_GBs": by / med / 1e6}
     print(f"gate forward         {v:7s} median {med:.3f} ms  min {mn:.3f} ms  {fl / med / 1e9:6.0f} TF  {by / med / 1e6:6.0f} GB/s", flush=True)
+# K5 in one launch against the unfused pair (Linear on the default tiling, then act + LayerNorm + normalised copy)
+for name, k, d_out in (("layer 256 -> 256", 256, 256), ("layer 300 -> 32", 300, 32), ("layer 64 -> 64", 64, 64)):
+    x = torch.randn((n, k), generator=gen, device=dev)
+    w = torch.randn((d_out, k), generator=gen, device=dev) * 0.06
+    b = torch.randn(d_out, generator=gen, device=dev)
+    gamma, beta = torch.ones(d_out, device=dev), torch.zeros(d_out, device=dev)
+    rm = ops.row_absmax(x)
+    slot = torch.empty((n, d_out), device=dev)
+    z = torch.empty((n, d_out), device=dev)
+
+    def unfused():
+        if ops.tall_ok(n, d_out, (k,), True):
+            ops.gemm_tall((x,), ((w,),), True, b, out=z, rowmax=rm)
+        else:
+            ops.gemm(x, w, trans_b=True, bias=b, out=z)
+        return ops.act_layernorm(z, gamma, beta, want_norm=True, drop_p=0.1, seed=7, yn_out=slot)
+
+    def fused():
+        return ops.linear_act_layernorm_fwd((x,), (w,), b, gamma, beta, 0.01, 1e-5, 1e-12, 0.1, 7, yn_out=slot, rowmax=rm)
+    y0, _ = unfused()
+    y1 = fused()[0]
+    print(f"{name}: max |fused - unfused| = {float((y1 - y0).abs().max()):.2e}")
+    tu, tf = [], []
+    with torch.no_grad():
+        for _ in range(args.rounds):
+            tu += ev_time(unfused, args.reps)
+            tf += ev_time(fused, args.reps)
+    for tag, tt in (("unfused pair", tu), ("fused launch", tf)):
+        med = float(np.median(tt))
+        res[f"{name} [{tag}]"] = {"median_ms": med, "min_ms": float(np.min(tt))}
+        print(f"{name:20s} {tag:13s} median {med:.3f} ms  min {float(np.min(tt)):.3f} ms", flush=True)
+    del x, w, slot, z
 if args.json:
     json.dump(res, open(args.json, "w"), indent=1)
