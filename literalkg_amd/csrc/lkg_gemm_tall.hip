@@ -49,6 +49,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_ACTLN = 2 };
 
+// In-kernel stamps (a DIAGNOSTIC build only: LKG_EXTRA_HIPCC_FLAGS=-DLKG_WS_STAMPS; tools/ws_stamps.py): every wave sums the
+// cycles it spends waiting for memory, waiting at the step barrier and working; lane 0 adds the sums to the buffer the
+// caller hands in as the gate's (otherwise unused) z_out of a PLAIN product.  No stamp executes in the product build.
+#ifdef LKG_WS_STAMPS
+#define LKG_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define LKG_STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define LKG_STAMP(var)
+#define LKG_STAMP_ADD(acc, a, b)
+#endif
+
+
 struct TallArgs {
     long m;
     int n;                       // GEMM width (stacked width 2 d for the gate)
@@ -185,13 +197,20 @@ __global__ __launch_bounds__(BN) void b_planes_kernel(BDesc b, int ktiles_total,
 // mids): FOUR waves of 64 x 128 -- one wave per SIMD and workgroup, two workgroups per CU at up to 256 VGPRs each, 24 MFMAs
 // per wave and barrier instead of 12, 48 KB of fragment reads per step instead of 64 KB, no scaled operand copies: while one
 // workgroup of a CU stores its tile the other has the matrix pipe of all four SIMDs to itself.
-template <int BN, int EPI, bool ONE, int WN = 64>
-__global__ __launch_bounds__(2 * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2), WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2))))
+// TM_: rows per tile.  128 (the forms above), or 256 with 64 x 128 wave tiles: EIGHT waves (4 x 2), one workgroup per CU.  Why:
+// in-kernel stamps (tools/ws_stamps.py, profiles/r04_tall_stamps.log) put the 128-row forms at the rate at which a CU's vector
+// memory pipe takes requests -- per 128-row tile at K = 256 it moves 128 KB of A, 256 KB of B planes (re-streamed from the
+// L2 for every row tile: HALF of the bytes) and 128 KB of C, ~18 B per cycle; waves spend 20 % of a step issuing requests
+// and an epilogue of 19 k cycles on 16 store instructions.  A 256-row tile reads B's planes once per 256 rows.
+template <int BN, int EPI, bool ONE, int WN = 64, int TM_ = 128>
+__global__ __launch_bounds__((TM_ / 64) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2), WN == 128 ? 2 : (ONE ? (BN == 128 ? 3 : 4) : 2))))
 void gemm_tall_kernel(TallArgs g) {
     static_assert(WN == 64 || (WN == 128 && BN == 256 && ONE), "64 x 128 wave tiles: 256-column tiles, one accumulator");
+    static_assert(TM_ == 128 || (TM_ == 256 && WN == 128), "256-row tiles: 64 x 128 wave tiles");
+    constexpr int TM = TM_;                       // (shadows the namespace's 128 for everything below)
     constexpr bool PRE = WN == 128;               // mid planes hold the residual itself (split2<true>)
     constexpr int NJ = WN / 32;                   // 32-column blocks per wave
-    constexpr int NT = 2 * (BN / WN) * 64;        // threads
+    constexpr int NT = (TM / 64) * (BN / WN) * 64;        // threads
     constexpr int EPT = TM * TK / NT;             // A floats per thread per k tile: 4 (BN = 256) or 8 (BN = 128)
     constexpr int TPR = TK / EPT;                 // threads per A row
     constexpr int APL = TM * TK, BPL = BN * TK;   // halves per plane
@@ -737,7 +756,20 @@ void gemm_tall_kernel(TallArgs g) {
     // the other one) -> LDS-DMA of B(t+1) into the other buffer and of A(t+3) into the ring slot tile t just left ->
     // fragment reads + 12 MFMAs of tile t, with the split of tile t+1 (ring -> planes of the other buffer) in their
     // shadow.  Past the last tile the staged / fetched tiles are duplicates of the last one (in bounds, never read).
+#ifdef LKG_WS_STAMPS
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_step = 0, t_epi = 0, t_pro = 0, n_steps = 0;
+#define LKG_WAIT_BARRIER(N)                                                                                  \
+    do {                                                                                                     \
+        LKG_STAMP(w0_);                                                                                      \
+        asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");                                     \
+        LKG_STAMP(w1_);                                                                                      \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+        LKG_STAMP(w2_);                                                                                      \
+        LKG_STAMP_ADD(t_wait, w0_, w1_); LKG_STAMP_ADD(t_bar, w1_, w2_);                                     \
+    } while (0)
+#else
 #define LKG_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
     // A tile's FIRST k step reads buffer 1: the epilogue's transposes use the first 32 KB of the staging LDS (buffer 0 and the A
     // planes of buffer 1), so the next tile's first B planes -- requested before that epilogue -- land beyond them.
     auto request_first = [&](bool issue) {         // the loads that open a tile: B(0) -> buffer 1, A(0..2) -> the ring
@@ -752,6 +784,7 @@ void gemm_tall_kernel(TallArgs g) {
     request_first(true);
     bool first_tile = true;
     while (true) {
+        LKG_STAMP(p0_);
         if (!first_tile) {                         // (workgroup-uniform) re-derive what the epilogue was not asked to carry
             rethread();
             tile_regs(slot);
@@ -779,17 +812,27 @@ void gemm_tall_kernel(TallArgs g) {
         ring_read(0);                              // (its own pieces: no barrier between the DMA and the read-back)
         ring_wait();
         stage_only(smem + BUF);
+        LKG_STAMP(p1_);
+        LKG_STAMP_ADD(t_pro, p0_, p1_);
         int slot_f = 0, slot_s = 1;                // ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged
         for (int gt = 0; gt < n_tiles; ++gt) {
             plan_a(2);
             plan_stage();
             _Float16 *cur = smem + ((gt + 1) & 1) * BUF, *nxt = smem + (gt & 1) * BUF;
             if constexpr (NA == 1) LKG_WAIT_BARRIER(1); else LKG_WAIT_BARRIER(2);
+            LKG_STAMP(k0_);
             ring_read(slot_s);
             issue_b(gt + 1, nxt);
             issue_a(slot_f);
             ring_wait();
+            LKG_STAMP(k1_);
             step(cur, nxt, true);
+#ifdef LKG_WS_STAMPS
+            asm volatile("s_nop 0" :: "v"(acc[1][NJ - 1][0]));
+            ++n_steps;
+#endif
+            LKG_STAMP(k2_);
+            LKG_STAMP_ADD(t_issue, k0_, k1_); LKG_STAMP_ADD(t_step, k1_, k2_);
             slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
             slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
         }
@@ -806,10 +849,20 @@ void gemm_tall_kernel(TallArgs g) {
             tile_prefetch();
             request_first(true);
         }
+        LKG_STAMP(e0_);
         epilogue(e_m0, e_n0);
+        LKG_STAMP(e1_);
+        LKG_STAMP_ADD(t_epi, e0_, e1_);
         if (!more) break;
         __syncthreads();     // the transposes are done with buffer 1's A planes and the tile's LDS scalars: the next tile moves in
     }
+#ifdef LKG_WS_STAMPS
+    if (EPI == EPI_PLAIN && g.z_out && (threadIdx.x & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.z_out);
+        atomicAdd(dbg + 16, t_wait); atomicAdd(dbg + 17, t_bar); atomicAdd(dbg + 18, t_issue); atomicAdd(dbg + 19, t_step);
+        atomicAdd(dbg + 20, t_epi); atomicAdd(dbg + 21, t_pro); atomicAdd(dbg + 22, n_steps);
+    }
+#endif
 #undef LKG_WAIT_BARRIER
 }
 
@@ -854,17 +907,6 @@ static_assert(WS_LDS_BYTES <= 160 * 1024, "one workgroup per CU: at most 160 KB 
 struct WsWalk {            // position in the item stream: row tile (index into this workgroup's stripe), column tile, k tile
     int rt, tn, panel, tk, gt;
 };
-
-// In-kernel stamps (a DIAGNOSTIC build only: LKG_EXTRA_HIPCC_FLAGS=-DLKG_WS_STAMPS; tools/ws_stamps.py): every wave sums the
-// cycles it spends waiting for memory, waiting at the step barrier and working; lane 0 adds the sums to the buffer the
-// caller hands in as the gate's (otherwise unused) z_out of a PLAIN product.  No stamp executes in the product build.
-#ifdef LKG_WS_STAMPS
-#define LKG_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define LKG_STAMP_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define LKG_STAMP(var)
-#define LKG_STAMP_ADD(acc, a, b)
-#endif
 
 // Position in the item stream, advanced by one item.  (Plain functions with value / reference parameters instead of lambdas
 // capturing by reference: with the loader written as lambdas hipcc kept 39 closures and their captured variables in scratch.)
@@ -1487,7 +1529,8 @@ inline int total_ktiles(int n_panels, const int32_t *ka) {
 // variant: 0 "256x2" (two accumulators, 128 x 256 tiles), 1 "128x1", 2 "256x1" (one accumulator, 8 waves of 64 x 64),
 // 3 "256x1w" (one accumulator, prescaled mids, 4 waves of 64 x 128), 4 "ws" (wave-specialised: one 8-wave workgroup per CU,
 // loader waves for the A stream, compute waves of 64 x 128 for B + MFMA; the only form of the act + LayerNorm epilogue;
-// outputs of at most 128 columns without that epilogue stay on "128x1").  Chosen PER CALL: bits 8-15 of the `epilogue`
+// outputs of at most 128 columns without that epilogue stay on "128x1"), 5 "256r" (256-row tiles: 8 waves of 64 x 128, one
+// workgroup per CU -- B's planes cross the CU's vector memory pipe once per 256 rows).  Chosen PER CALL: bits 8-15 of the `epilogue`
 // argument hold variant + 1 (0 = the library's default), so a test or a tool runs any variant next to any other in one
 // process and nothing in the environment selects code (LKG_TALL_VARIANT is gone).
 inline int variant_of(int epilogue_arg) {
@@ -1543,7 +1586,7 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
                      void *stream, const LnExtra *ln) {
     const int32_t epilogue_arg = epilogue;          // bits 0-7: the epilogue, bits 8-15: variant + 1 (0 = default)
     epilogue = epilogue_arg & 0xff;
-    LKG_REQUIRE((epilogue_arg >> 16) == 0 && ((epilogue_arg >> 8) & 0xff) <= 5, "lkg_gemm_tall_f32: unknown variant in the "
+    LKG_REQUIRE((epilogue_arg >> 16) == 0 && ((epilogue_arg >> 8) & 0xff) <= 6, "lkg_gemm_tall_f32: unknown variant in the "
                 "epilogue argument (0x%x)", epilogue_arg);
     LKG_REQUIRE(m >= 0 && n > 0 && n_panels >= 1 && n_panels <= MAX_PANELS, "lkg_gemm_tall_f32: bad sizes");
     LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE || (epilogue == EPI_ACTLN && ln),
@@ -1570,7 +1613,9 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     geometry(n, epilogue_arg, bn, tiles_n);
     const int variant = variant_of(epilogue_arg);
     const bool ws = (variant == 4 || epilogue == EPI_ACTLN) && bn == 256;     // wave-specialised (the fused layer epilogue: always)
-    const bool wide = (variant == 3 && bn == 256) || ws;                      // prescaled mid planes
+    const bool tall256 = variant == 5 && bn == 256 && !ws;                    // 256-row tiles, 8 waves of 64 x 128
+    const bool wide = (variant == 3 && bn == 256) || ws || tall256;           // prescaled mid planes
+    const int tm_rows = tall256 ? 256 : TM;
     TallArgs g{};
     BDesc bd{};
     g.m = m; g.n = n; g.n_panels = n_panels;
@@ -1588,7 +1633,7 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
         }
     }
     g.ktiles_total = total_ktiles(n_panels, ka);
-    g.tiles_m = (int)((m + TM - 1) / TM);
+    g.tiles_m = (int)((m + tm_rows - 1) / tm_rows);
     g.tiles_n = tiles_n;
     LKG_REQUIRE((long)g.tiles_m * g.tiles_n < INT32_MAX, "lkg_gemm_tall_f32: too many tiles");
     _Float16 *planes = reinterpret_cast<_Float16 *>(workspace);
@@ -1604,19 +1649,20 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     g.a_rowmax = a_rowmax; g.bp = planes; g.eb = eb; g.alpha = alpha; g.beta = beta; g.c = c; g.ldc = ldc; g.bias = bias;
     g.x = gate_x; g.ldx = ld_x; g.g_out = gate_g; g.ldg = ld_g; g.z_out = gate_z; g.ldz = ld_z;
     const long n_tiles_mn = (long)g.tiles_m * g.tiles_n;
-    auto lds_bytes = [](int bn_, int nt_) {
-        return 2 * (2 * TM * TK + 2 * bn_ * TK) * 2 + 3 * TM * TK * 4 + TM * 4 + 2 * bn_ * 4 +
-               (nt_ + TM + 2 * bn_) * 4;       // + the landing area of the next tile's scalars
+    auto lds_bytes = [](int bn_, int nt_, int tm_) {
+        return 2 * (2 * tm_ * TK + 2 * bn_ * TK) * 2 + 3 * tm_ * TK * 4 + tm_ * 4 + 2 * bn_ * 4 +
+               (nt_ + tm_ + 2 * bn_) * 4;       // + the landing area of the next tile's scalars
     };
-    const int lds = lds_bytes(bn, wide ? 256 : 2 * bn);
+    const int lds = lds_bytes(bn, tall256 ? 512 : (wide ? 256 : 2 * bn), tm_rows);
     const bool one = variant != 0;
-#define LKG_TALL_GO(BN_, EPI_, ONE_) LKG_TALL_GO_W(BN_, EPI_, ONE_, 64)
-#define LKG_TALL_GO_W(BN_, EPI_, ONE_, WN_)                                                                                   \
+#define LKG_TALL_GO(BN_, EPI_, ONE_) LKG_TALL_GO_T(BN_, EPI_, ONE_, 64, 128)
+#define LKG_TALL_GO_W(BN_, EPI_, ONE_, WN_) LKG_TALL_GO_T(BN_, EPI_, ONE_, WN_, 128)
+#define LKG_TALL_GO_T(BN_, EPI_, ONE_, WN_, TM_)                                                                                   \
     do {                                                                                                               \
         static bool raised = false;                                                                                    \
         static int resident = 0;      /* workgroups of this kernel the device holds at once (occupancy x CUs) */       \
         if (!raised && lds > 48 * 1024) {                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_, WN_>),                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tall_kernel<BN_, EPI_, ONE_, WN_, TM_>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {                  \
                 lkg_set_error("lkg_gemm_tall_f32: cannot raise the dynamic LDS limit");                                \
                 return LKG_ERR_HIP;                                                                                    \
@@ -1627,8 +1673,8 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
             int dev_ = 0, per_cu_ = 0, cus_ = 0;                                                                       \
             if (hipGetDevice(&dev_) != hipSuccess ||                                                                   \
                 hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess ||             \
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_kernel<BN_, EPI_, ONE_, WN_>,              \
-                                                             2 * (BN_ / WN_) * 64, lds) != hipSuccess ||               \
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, gemm_tall_kernel<BN_, EPI_, ONE_, WN_, TM_>,              \
+                                                             (TM_ / 64) * (BN_ / WN_) * 64, lds) != hipSuccess ||               \
                 per_cu_ < 1 || cus_ < 1) {                                                                             \
                 lkg_set_error("lkg_gemm_tall_f32: cannot size the persistent grid");                                   \
                 return LKG_ERR_HIP;                                                                                    \
@@ -1642,7 +1688,7 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
            counters); persistent workgroups drift apart and every row tile's inputs cross the fabric twice (1.98 x) */   \
         const bool one_tile_ = g.tiles_n > 1;                                                                          \
         const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
-        hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_, WN_>), grid, dim3(2 * (BN_ / WN_) * 64), lds, s, g);     \
+        hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_, WN_, TM_>), grid, dim3((TM_ / 64) * (BN_ / WN_) * 64), lds, s, g);     \
     } while (0)
     if (ws) {
         if (ln) {
@@ -1674,6 +1720,9 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
         else if (epilogue == EPI_ACTLN) LKG_TALL_GO_WS(EPI_ACTLN);
         else LKG_TALL_GO_WS(EPI_PLAIN);
 #undef LKG_TALL_GO_WS
+    } else if (tall256) {
+        if (epilogue == EPI_GATE) LKG_TALL_GO_T(256, EPI_GATE, true, 128, 256);
+        else LKG_TALL_GO_T(256, EPI_PLAIN, true, 128, 256);
     } else if (wide) {
         if (epilogue == EPI_GATE) LKG_TALL_GO_W(256, EPI_GATE, true, 128);
         else LKG_TALL_GO_W(256, EPI_PLAIN, true, 128);
@@ -1690,6 +1739,7 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     }
 #undef LKG_TALL_GO
 #undef LKG_TALL_GO_W
+#undef LKG_TALL_GO_T
     LKG_CHECK_LAUNCH("lkg_gemm_tall_f32");
     return LKG_OK;
 }

@@ -581,7 +581,7 @@ def tall_ok(m: int, n: int, ks: Sequence[int], single_panel_too: bool = False) -
     return n * sum(ks) <= (1 << 22)
 
 
-TALL_VARIANTS = {"256x2": 0, "128x1": 1, "256x1": 2, "256x1w": 3, "ws": 4}      # lkg_gemm_tall_f32: bits 8-15 of `epilogue` = id + 1
+TALL_VARIANTS = {"256x2": 0, "128x1": 1, "256x1": 2, "256x1w": 3, "ws": 4, "256r": 5}      # lkg_gemm_tall_f32: bits 8-15 of `epilogue` = id + 1
 DEFAULT_TALL_VARIANT: Optional[str] = None      # None = the library's default; tests / tools set a key to steer whole modules
 
 

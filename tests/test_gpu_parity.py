@@ -327,7 +327,7 @@ def test_gemm_tall_f16x2_engine_is_f32_accurate(ops, gpu_device, ks, n, tb):
     assert err4 <= max(10.0 * f32, 5e-6), (err4, f32)
 
 
-@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "128x1", "ws"])
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "128x1", "ws", "256r"])
 @pytest.mark.parametrize("ks,n,tb", [((256,), 256, True), ((256, 2, 300), 256, True), ((512,), 300, True), ((30, 7), 50, False),
                                      ((40,), 200, True), ((16,), 600, True), ((3, 5, 2), 130, False)])
 def test_gemm_tall_every_tiling_variant_is_f32_accurate(ops, gpu_device, variant, ks, n, tb):
@@ -361,7 +361,7 @@ def test_gemm_tall_every_tiling_variant_is_f32_accurate(ops, gpu_device, variant
     assert float(got3[9].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "ws"])
+@pytest.mark.parametrize("variant", ["256x2", "256x1", "256x1w", "ws", "256r"])
 def test_fused_gate_every_tiling_variant(L, ops, O, gpu_device, variant):
     """The gate's one-launch stacked product (blend epilogue) on every 256-column tiling against the oracle's gate."""
     torch.manual_seed(4)

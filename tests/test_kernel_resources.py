@@ -39,10 +39,10 @@ def test_tall_gemm_keeps_two_workgroups_per_cu():
     asm = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", "-",
                           os.path.join(CSRC, "lkg_gemm_tall.hip")], check=True, capture_output=True, text=True).stdout
     found = {}
-    for name, vgpr in re.findall(r"\.name:\s+(\S*gemm_tall_kernelILi256ELi[01]ELb1ELi(?:64|128)E\S*)\n(?:.*\n)*?.*?\.vgpr_count:\s+(\d+)", asm):
+    for name, vgpr in re.findall(r"\.name:\s+(\S*gemm_tall_kernelILi256ELi[01]ELb1ELi(?:64|128)ELi(?:128|256)E\S*)\n(?:.*\n)*?.*?\.vgpr_count:\s+(\d+)", asm):
         found[name] = int(vgpr)
-    narrow = {k: v for k, v in found.items() if "ELb1ELi64E" in k}
-    wide = {k: v for k, v in found.items() if "ELb1ELi128E" in k}
-    assert len(narrow) == 2 and len(wide) == 2, found
+    narrow = {k: v for k, v in found.items() if "ELb1ELi64ELi128E" in k}
+    wide = {k: v for k, v in found.items() if "ELb1ELi128ELi" in k}      # 64 x 128 wave tiles: 128- and 256-row tiles
+    assert len(narrow) == 2 and len(wide) == 4, found
     assert all(v <= 128 for v in narrow.values()), narrow
     assert all(v <= 256 for v in wide.values()), wide

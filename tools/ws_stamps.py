@@ -34,3 +34,12 @@ for k in (64, 256, 558):
     print(f"   compute waves: wait for B {v[0] / c_items:8.0f}  barrier {v[1] / c_items:8.0f}  step (reads + 24 MFMAs) {v[2] / c_items:8.0f}  "
           f"epilogue per step {v[3] / c_items:8.0f} (per tile {v[3] / c_items * ((k + 15) // 16):8.0f})")
     print(f"   loader waves : barrier {v[8] / l_items:8.0f}  issue {v[9] / l_items:8.0f}  wait for A {v[10] / l_items:8.0f}  stage {v[11] / l_items:8.0f}")
+    for variant in ("256x1", "256x1w", "256r"):
+        dbg.zero_()
+        ops.gemm_tall((x,), ((w,),), True, None, out=out, rowmax=rm, variant=variant, keep=(None, dbg))
+        torch.cuda.synchronize()
+        v = dbg.view(-1)[:64].view(torch.int64).cpu().tolist()
+        ns = max(v[22], 1)
+        kt = (k + 15) // 16
+        print(f"   {variant:7s} per wave and k step: wait (vmcnt + lgkmcnt) {v[16] / ns:7.0f}  barrier {v[17] / ns:7.0f}  ring read + requests {v[18] / ns:7.0f}  "
+              f"MFMAs + split {v[19] / ns:7.0f} | per tile: epilogue {v[20] / ns * kt:8.0f}  tile opening {v[21] / ns * kt:8.0f}")
