@@ -571,10 +571,12 @@ int lkg_gemm_tall_f32(int64_t m, int32_t n, int32_t n_panels, const float *const
  *     z  = sum_p A_p W_p^T + bias                      (nn.Linear over a column-concatenated input, model.py:108-110, 116-123)
  *     y  = Dropout_p(LayerNorm(LeakyReLU_slope(z)))    (model.py:111, 161; eps, gamma, beta: nn.LayerNorm's)
  *     yn = y / max(|y|_2, norm_eps)                    (F.normalize, model.py:305)
- * for output widths n <= 256: the 128 x 256 tile of the wave-specialised tall GEMM holds whole rows, the row statistics are
- * three sums exchanged between the two compute waves of a row.  z is NOT written (nor read back by a second kernel): one HBM
- * pass fewer than lkg_gemm_tall_f32 + lkg_act_layernorm_fwd_f32, which it matches to fp32 rounding (the sums run in another
- * order).  y and yn are nullable (not both); save_mean / save_rstd float[m] are what lkg_act_layernorm_bwd_f32 needs beside a
+ * for output widths n <= 256 and at most two K-panels: the 128 x 256 tile of the tall GEMM holds whole rows; its epilogue
+ * sends them through LDS in slabs of 16 rows, row-major, and runs the row-wise kernel's own arithmetic on them (one wave per
+ * row, the same lane <-> column map and reduction tree), so y, yn, mean and rstd are BIT-IDENTICAL to lkg_gemm_tall_f32 (its
+ * default tiling) followed by lkg_act_layernorm_fwd_f32 whenever that kernel takes its 16-byte path (n % 4 == 0, aligned
+ * rows), and equal to fp32 rounding otherwise.  z is NOT written (nor read back by a second kernel): one HBM pass fewer.
+ * y and yn are nullable (not both); save_mean / save_rstd float[m] are what lkg_act_layernorm_bwd_f32 needs beside a
  * recomputed z.  The dropout mask is lkg_act_layernorm_fwd_f32's (same seed, same mask).  Arguments a .. a_rowmax, workspace:
  * as for lkg_gemm_tall_f32 (w: one [n, ka[p]] block per panel, nn.Linear layout).                                         */
 int64_t lkg_linear_act_layernorm_workspace(int32_t n, int32_t n_panels, const int32_t *ka);

@@ -292,7 +292,7 @@ void gemm_tall_kernel(TallArgs g) {
         grow = min(m0 + arow, g.m - 1);                       // clamped: rows past m are computed and never stored
         rowp0 = pa0 + 4ul * (unsigned long)(grow * ld0 + akc * EPT);
         rowp1 = pa1 + 4ul * (unsigned long)(grow * ld1 + akc * EPT);
-        rowp2 = pa2 + 4ul * (unsigned long)(grow * ld2 + akc * EPT);
+        if constexpr (EPI != EPI_ACTLN) rowp2 = pa2 + 4ul * (unsigned long)(grow * ld2 + akc * EPT);      // (the fused layer: <= 2 panels)
         bsrc = reinterpret_cast<const uint4 *>(g.bp) + (long)tn * g.ktiles_total * (2 * BPL / 8) + t;
     };
     // the tile's scalars from global memory: requested here (before the previous tile's epilogue) by LDS-DMA, one dword per
@@ -685,6 +685,123 @@ void gemm_tall_kernel(TallArgs g) {
                     flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
                     __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
                 }
+        } else if constexpr (EPI == EPI_ACTLN) {
+            // K5 in the GEMM's epilogue (model.py:108-111, 161, 305): LeakyReLU -> LayerNorm -> dropout (+ the
+            // L2-normalised copy).  The tile holds whole rows (n <= 256, one column tile), but in MFMA layout a row is spread
+            // over the BN / WN waves of a row half -- so the tile goes through LDS in SLABS of 16 rows x 256 columns (inside the
+            // area the other epilogues' transposes use): the waves that own a slab's rows write z = A B^T + bias into it row-major
+            // (exactly what the plain epilogue would have stored), then ALL waves of the workgroup take four rows each and run
+            // the row-wise kernel's own arithmetic on them -- one wave per row, 16 bytes per lane, the same lane <-> column map and
+            // the same reduction tree as lkg_act_layernorm_fwd_f32: y, yn, mean and rstd are BIT-IDENTICAL to the unfused pair.
+            // Registers: one 16-value block at a time, like the plain epilogue (three in-register designs spilled 80-230
+            // VGPRs: hipcc kept per-row values, rewritten accumulators and their common subexpressions alive from pass to pass).
+            // Stores: whole 1 KB rows per instruction.  Slabs of 16 rows (gamma / beta ride in LDS behind them): 16 workgroup
+            // barriers per tile.
+            static_assert(EPI != EPI_ACTLN || (ONE && BN == 256 && TM == 128), "the fused layer epilogue: one accumulator, 128 x 256 tiles");
+            // The epilogue's own operands (19 dwords of kernel arguments) are read HERE, through an opaque pointer to the
+            // kernel-argument segment: as fields of `g` they are loaded at kernel entry and sit in SGPRs through the k loop, the
+            // scalar file overflows into VGPR lanes and the 128-VGPR budget with them (6 spilled VGPRs in the tile-opening code).
+            const TallArgs *L = (const TallArgs *)__builtin_amdgcn_kernarg_segment_ptr();      // (a cast across address spaces)
+            asm volatile("" : "+s"(L));
+            constexpr int NWAVES = NT / 64, SROWS = 16, RPW = SROWS / NWAVES;  // rows of a slab per wave: 2 (8 waves)
+            float *slab = reinterpret_cast<float *>(smem);                     // [16][BN], then gamma[BN], beta[BN]: 18 KB
+            float *gb_s = slab + SROWS * BN;
+            const int c4 = 4 * lane;                                           // this lane's four columns in the row phase
+            if (wave < 2) {                                                    // gamma / beta of the layer: into LDS once per tile
+                const float *src = wave == 0 ? L->gamma : L->beta_ln;            // (visible behind the first slab's barrier)
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) gb_s[wave * BN + c4 + k] = c4 + k < g.n ? src[c4 + k] : 0.f;
+            }
+            const float inv_keep = L->drop_p > 0.f ? 1.f / (1.f - L->drop_p) : 1.f;
+            const bool vec_y = g.c && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0);
+            const bool vec_n = L->yn && (L->ldyn % 4 == 0) && ((reinterpret_cast<uintptr_t>(L->yn) & 15) == 0);
+            auto slab_pass = [&](auto S) {
+                // slab sl = rows 16 sl .. 16 sl + 15 of the tile: wave row sl / 4, block row (sl / 2) & 1, registers 8 h .. 8 h + 7
+                constexpr int sl = decltype(S)::value, i = (sl >> 1) & 1, h = sl & 1;
+                if (wm == (sl >> 2)) {                                         // (wave-uniform) this wave owns rows of the slab
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int sc = wn * WN + j * 32 + (lane & 31);
+                        const int eb_j = eb_s[sc];
+                        const float bias_j = bias_s[sc];
+    #pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int dr = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);           // row inside the slab
+                            slab[dr * BN + sc] = g.alpha * ldexpf(acc[i][j][8 * h + q], -(ea_s[wm * 64 + i * 32 + 16 * h + dr] + eb_j)) + bias_j;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __syncthreads();
+    #pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int row = wave * RPW + rr;                           // row of the slab
+                    const long grow = m0 + sl * SROWS + row;
+                    const float4 z4 = *reinterpret_cast<const float4 *>(slab + row * BN + c4);
+                    const float4 gam4 = *reinterpret_cast<const float4 *>(gb_s + c4), bet4 = *reinterpret_cast<const float4 *>(gb_s + BN + c4);
+                    float a[4] = {z4.x, z4.y, z4.z, z4.w};
+                    const float gm[4] = {gam4.x, gam4.y, gam4.z, gam4.w}, bt[4] = {bet4.x, bet4.y, bet4.z, bet4.w};
+                    float s_ = 0.f;
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[k] = a[k] > 0.f ? a[k] : a[k] * L->slope;
+                        s_ += c4 + k < g.n ? a[k] : 0.f;
+                    }
+                    const float mean = wave_sum(s_) / (float)g.n;
+                    float q_ = 0.f;
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float c = c4 + k < g.n ? a[k] - mean : 0.f;
+                        q_ = fmaf(c, c, q_);
+                    }
+                    const float rstd = 1.f / sqrtf(wave_sum(q_) / (float)g.n + L->ln_eps);
+                    const unsigned rkey = drop_row_key(L->seed, (unsigned long long)grow);
+                    float nn = 0.f;
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float o = (a[k] - mean) * rstd * gm[k] + bt[k];
+                        if (L->drop_p > 0.f) o *= drop_scale(rkey, (unsigned)(c4 + k), L->drop_p, inv_keep);
+                        a[k] = o;
+                        nn += c4 + k < g.n ? o * o : 0.f;
+                    }
+                    const float inv = 1.f / fmaxf(sqrtf(wave_sum(nn)), L->norm_eps);
+                    if (grow < g.m) {                                          // (wave-uniform)
+                        if (lane == 0) {
+                            L->mean[grow] = mean;
+                            L->rstd[grow] = rstd;
+                        }
+                        if (g.c) {
+                            float *dst = g.c + grow * g.ldc + c4;
+                            if (vec_y && c4 + 3 < g.n) {
+                                *reinterpret_cast<float4 *>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+                            } else {
+    #pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (c4 + k < g.n) dst[k] = a[k];
+                            }
+                        }
+                        if (L->yn) {
+                            float *dst = L->yn + grow * L->ldyn + c4;
+                            if (vec_n && c4 + 3 < g.n) {
+                                *reinterpret_cast<float4 *>(dst) = make_float4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+                            } else {
+    #pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (c4 + k < g.n) dst[k] = a[k] * inv;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();                                               // the next slab overwrites this one
+            };
+            slab_pass(std::integral_constant<int, 0>{});
+            slab_pass(std::integral_constant<int, 1>{});
+            slab_pass(std::integral_constant<int, 2>{});
+            slab_pass(std::integral_constant<int, 3>{});
+            slab_pass(std::integral_constant<int, 4>{});
+            slab_pass(std::integral_constant<int, 5>{});
+            slab_pass(std::integral_constant<int, 6>{});
+            slab_pass(std::integral_constant<int, 7>{});
         } else {
             // gate: of every pair of tile column blocks, block 2 pr holds g and block 2 pr + 1 holds z of the SAME output columns
             const int d = g.n / 2;
@@ -1591,6 +1708,8 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     LKG_REQUIRE(m >= 0 && n > 0 && n_panels >= 1 && n_panels <= MAX_PANELS, "lkg_gemm_tall_f32: bad sizes");
     LKG_REQUIRE(epilogue == EPI_PLAIN || epilogue == EPI_GATE || (epilogue == EPI_ACTLN && ln),
                 "lkg_gemm_tall_f32: unknown epilogue %d", epilogue);
+    LKG_REQUIRE(epilogue != EPI_ACTLN || (n_panels <= 2 || ((epilogue_arg >> 8) & 0xff) == 5),
+                "lkg_linear_act_layernorm_fwd_f32: at most two K-panels");
     LKG_REQUIRE(epilogue != EPI_ACTLN || (n <= 256 && alpha == 1.f && beta == 0.f && ln->gamma && ln->beta && ln->mean &&
                                           ln->rstd && (c || ln->yn) && (!ln->yn || ln->ldyn >= n) && ln->drop_p >= 0.f &&
                                           ln->drop_p < 1.f),
@@ -1612,7 +1731,7 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     int bn, tiles_n;
     geometry(n, epilogue_arg, bn, tiles_n);
     const int variant = variant_of(epilogue_arg);
-    const bool ws = (variant == 4 || epilogue == EPI_ACTLN) && bn == 256;     // wave-specialised (the fused layer epilogue: always)
+    const bool ws = variant == 4 && bn == 256;                                // wave-specialised
     const bool tall256 = variant == 5 && bn == 256 && !ws;                    // 256-row tiles, 8 waves of 64 x 128
     const bool wide = (variant == 3 && bn == 256) || ws || tall256;           // prescaled mid planes
     const int tm_rows = tall256 ? 256 : TM;
@@ -1690,11 +1809,11 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
         const dim3 grid((unsigned)std::min<long>((n_tiles_mn + 7) / 8 * 8, one_tile_ ? (1L << 30) : (long)resident));   \
         hipLaunchKernelGGL((gemm_tall_kernel<BN_, EPI_, ONE_, WN_, TM_>), grid, dim3((TM_ / 64) * (BN_ / WN_) * 64), lds, s, g);     \
     } while (0)
+    if (ln) {
+        g.slope = ln->slope; g.ln_eps = ln->ln_eps; g.norm_eps = ln->norm_eps; g.drop_p = ln->drop_p; g.seed = ln->seed;
+        g.gamma = ln->gamma; g.beta_ln = ln->beta; g.yn = ln->yn; g.ldyn = ln->ldyn; g.mean = ln->mean; g.rstd = ln->rstd;
+    }
     if (ws) {
-        if (ln) {
-            g.slope = ln->slope; g.ln_eps = ln->ln_eps; g.norm_eps = ln->norm_eps; g.drop_p = ln->drop_p; g.seed = ln->seed;
-            g.gamma = ln->gamma; g.beta_ln = ln->beta; g.yn = ln->yn; g.ldyn = ln->ldyn; g.mean = ln->mean; g.rstd = ln->rstd;
-        }
 #define LKG_TALL_GO_WS(EPI_)                                                                                           \
     do {                                                                                                               \
         static bool raised = false;                                                                                    \
@@ -1726,6 +1845,8 @@ static int tall_call(int64_t m, int32_t n, int32_t n_panels, const float *const 
     } else if (wide) {
         if (epilogue == EPI_GATE) LKG_TALL_GO_W(256, EPI_GATE, true, 128);
         else LKG_TALL_GO_W(256, EPI_PLAIN, true, 128);
+    } else if (epilogue == EPI_ACTLN) {
+        LKG_TALL_GO(256, EPI_ACTLN, true);       // (8 waves of 64 x 64, two workgroups per CU)
     } else if (epilogue == EPI_GATE) {
         if (bn == 256 && !one) LKG_TALL_GO(256, EPI_GATE, false);
         else if (bn == 256) LKG_TALL_GO(256, EPI_GATE, true);

@@ -158,6 +158,18 @@ class Aggregator(nn.Module):
         self.last_normalized = yn
         return y
 
+    def _linear_finish(self, xs, ws, bias):
+        """_finish(sum_i x_i @ w_i^T + bias): ONE launch when ops.FUSED_LAYER asks for it and the shape allows (whole rows in a
+        256-column tile), else the tall GEMM followed by the row-wise kernel (same bits either way)."""
+        if ops.FUSED_LAYER and xs[0].is_cuda and ops.fused_layer_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs]):
+            ln = self.layer_normalize
+            p = float(self.dropout) if self.training else 0.0
+            y, yn = ops.linear_act_layernorm(xs, ws, bias, ln.weight, ln.bias, want_norm=True, drop_p=p, yn_out=self.norm_out,
+                                             want_y=self.want_output)
+            self.last_normalized = yn
+            return y
+        return self._finish(ops.multi_linear(xs, ws, bias))
+
     def narrows(self) -> bool:
         """A gcn layer of at most half its input's width (the reference's default 300 -> 32): it projects first and aggregates
         out_dim columns (forward below)."""
@@ -175,6 +187,8 @@ class Aggregator(nn.Module):
                 # Same sums in another order (fp32 rounding only); the bias rides in the SpMM's epilogue.
                 p = ops.linear(ego, self.linear.weight, None)
                 return self._finish(att.aggregate(p, True, bias=self.linear.bias))
+            if not self.use_residual:
+                return self._linear_finish((A_in.aggregate(ego, True),), (self.linear.weight,), self.linear.bias)
             z = self._res_lin(self.linear, A_in.aggregate(ego, True), h0, lamda, alpha, l)
             return self._finish(z)
         if kind == "gin":
@@ -187,7 +201,7 @@ class Aggregator(nn.Module):
                 z = self._res_lin(self.linear, hi, h0, lamda, alpha, l)
             else:   # Linear over [ego | side] as two accumulating GEMMs, no cat
                 w = self.linear.weight
-                z = ops.multi_linear((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
+                return self._linear_finish((ego, side), (w[:, :self.in_dim], w[:, self.in_dim:]), self.linear.bias)
             return self._finish(z)
         if kind == "bi-interaction":
             # sum, product and (with the residual) both mixes (1 - a) hi + a linear_h0(h0) in ONE kernel, one for their

@@ -649,7 +649,7 @@ def gemm_tall(a_panels: Sequence[torch.Tensor], b_blocks: Sequence[Sequence[torc
 
 def fused_layer_ok(m: int, n: int, ks: Sequence[int]) -> bool:
     """Can lkg_linear_act_layernorm_fwd_f32 take this Linear + LeakyReLU + LayerNorm?  (whole rows in one 256-column tile)"""
-    return (_ENGINE in ("f16x2", "f16x2-all") and m >= TALL_MIN_ROWS and 1 <= len(ks) <= 3 and min(ks) > 0 and 1 <= n <= 256
+    return (_ENGINE in ("f16x2", "f16x2-all") and m >= TALL_MIN_ROWS and 1 <= len(ks) <= 2 and min(ks) > 0 and 1 <= n <= 256
             and n * sum(ks) <= (1 << 22))
 
 
@@ -1319,6 +1319,90 @@ def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS,
     if drop_p > 0 and seed is None:
         seed = new_seed()
     return _ActLayerNorm.apply(z, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed or 0, yn_out, want_y)
+
+
+# ----------------------------------------------------------------------------- K5 in one launch (opt-in)
+FUSED_LAYER = _os.environ.get("LKG_FUSED_LAYER", "0") not in ("", "0")
+"""Route Linear + LeakyReLU + LayerNorm (+ dropout + normalised copy) of an aggregation layer through ONE launch
+(lkg_linear_act_layernorm_fwd_f32) where its shape allows.  OFF by default: measured on MI355X (profiles/r04_tall_variants_c.log,
+1 M x 256 x 256 with dropout) the fused launch takes 1.26 ms against 1.15 ms for the tall GEMM followed by the row-wise
+kernel -- the HBM pass it saves (z written and read back) costs less than the epilogue's 16 workgroup barriers per tile and
+the matrix pipe idling behind them.  Results are bit-identical either way."""
+
+
+class _ShimCtx:
+    """What the backward passes of _ActLayerNorm / _MultiLinear read from their ctx, for reuse by _FusedLayer."""
+
+    def __init__(self, saved, **kw):
+        self.saved_tensors = tuple(saved)
+        self.__dict__.update(kw)
+
+
+class _FusedLayer(Function):
+    """(y, yn) = Dropout(LayerNorm(LeakyReLU(sum_i x_i @ w_i^T + bias))), normalised copy: model.py:108-111, 161, 305 in ONE
+    launch.  z is not kept: the backward recomputes it -- on the listed rows when the incoming gradients are row-sparse (the
+    last layers under a loss on <= 3B rows: a few thousand rows through the small-product engine), else with one tall GEMM --
+    and then runs the unfused pair's own backward passes."""
+
+    @staticmethod
+    def forward(ctx, bias, gamma, beta, n_terms, slope, eps, norm_eps, drop_p, seed, yn_out, want_y, want_norm, *xw):
+        xs, ws = xw[:n_terms], xw[n_terms:]
+        y, yn, mean, rstd = linear_act_layernorm_fwd(xs, ws, bias, gamma, beta, slope, eps, norm_eps, drop_p, seed,
+                                                     want_y=want_y, want_norm=want_norm, yn_out=yn_out)
+        ctx.save_for_backward(*xs, *ws, gamma, beta, mean, rstd, *([bias] if bias is not None else []),
+                              *([y] if y is not None else []))
+        ctx.meta = (n_terms, bias is not None, y is not None, (slope, norm_eps, drop_p, seed))
+        ctx.set_materialize_grads(False)
+        return y, yn
+
+    @staticmethod
+    def backward(ctx, gy, gyn):
+        n_terms, has_bias, has_y, cfg = ctx.meta
+        saved = list(ctx.saved_tensors)
+        xs, ws = saved[:n_terms], saved[n_terms:2 * n_terms]
+        gamma, beta, mean, rstd = saved[2 * n_terms:2 * n_terms + 4]
+        rest = saved[2 * n_terms + 4:]
+        bias = rest.pop(0) if has_bias else None
+        y = rest.pop(0) if has_y else None
+        none = (None,) * 12
+        if gy is None and gyn is None:
+            return none + (None,) * (2 * n_terms)
+        n, d = xs[0].shape[0], ws[0].shape[0]
+        # ---- z again: on the rows the gradients can be non-zero on, or everywhere
+        rows_n, rows_y = tagged_rows(gyn), tagged_rows(gy)
+        rows = union_rows(rows_y, rows_n) if (gy is None or rows_y is not None) and (gyn is None or rows_n is not None) else None
+        if rows_worth_compacting(rows, n):
+            ids = rows.compact_ids()
+            zc = None
+            for x, w in zip(xs, ws):
+                zc = gemm(gather_rows_range(x, ids, 0, n), w, trans_b=True, beta=0.0 if zc is None else 1.0, out=zc,
+                          bias=bias if zc is None else None)
+            keep = ids >= 0
+            z = torch.empty((n, d), dtype=torch.float32, device=zc.device)      # (only the listed rows are ever read)
+            z.index_copy_(0, ids[keep], zc[keep])
+        elif tall_ok(n, d, [x.shape[1] for x in xs], single_panel_too=True):
+            z = gemm_tall(xs, (ws,), True, bias)
+        else:
+            z = None
+            for x, w in zip(xs, ws):
+                z = gemm(x, w, trans_b=True, beta=0.0 if z is None else 1.0, out=z, bias=bias if z is None else None)
+        # ---- the unfused pair's own backward passes
+        gz, gg, gb = _ActLayerNorm.backward(_ShimCtx((z, gamma, beta, mean, rstd, *([y] if y is not None else [])), cfg=cfg),
+                                            gy, gyn)[:3]
+        need = ctx.needs_input_grad
+        lin = _MultiLinear.backward(_ShimCtx((*xs, *ws), n_terms=n_terms, has_bias=has_bias,
+                                             needs_input_grad=(need[0], False, *need[12:12 + 2 * n_terms])), gz)
+        return (lin[0], gg, gb) + none[3:] + tuple(lin[2:])
+
+
+def linear_act_layernorm(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], bias, gamma, beta, want_norm=True,
+                         slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS, drop_p: float = 0.0,
+                         seed: Optional[int] = None, yn_out: Optional[torch.Tensor] = None, want_y: bool = True):
+    """(y, yn) of a whole aggregation layer's dense part in one launch; see _FusedLayer / FUSED_LAYER."""
+    if drop_p > 0 and seed is None:
+        seed = new_seed()
+    return _FusedLayer.apply(bias, gamma, beta, len(xs), float(slope), float(eps), float(norm_eps), float(drop_p), seed or 0,
+                             yn_out, want_y, want_norm, *xs, *ws)
 
 
 # ----------------------------------------------------------------------------- concat without the copy

@@ -381,7 +381,7 @@ def test_fused_gate_every_tiling_variant(L, ops, O, gpu_device, variant):
 
 
 @pytest.mark.parametrize("m", [16384 + 5, 40_000])
-@pytest.mark.parametrize("ks,n", [((256,), 256), ((64, 64), 128), ((300,), 32), ((256, 2, 300), 200), ((40,), 7), ((128,), 256)])
+@pytest.mark.parametrize("ks,n", [((256,), 256), ((64, 64), 128), ((300,), 32), ((256, 300), 200), ((40,), 7), ((128,), 256), ((32,), 32)])
 @pytest.mark.parametrize("drop_p", [0.0, 0.25])
 def test_fused_layer_epilogue_matches_the_unfused_pair(ops, gpu_device, m, ks, n, drop_p):
     """K5 in one launch (lkg_linear_act_layernorm_fwd_f32: Linear + LeakyReLU + LayerNorm + dropout + normalised copy in the
@@ -401,6 +401,9 @@ def test_fused_layer_epilogue_matches_the_unfused_pair(ops, gpu_device, m, ks, n
     y0, yn0 = ops.act_layernorm(z, gamma, beta, want_norm=True, drop_p=drop_p, seed=seed)
     kept = (y0 != 0) == (y != 0)
     assert bool(kept.all()), "the two paths must draw the same dropout mask"
+    if n % 4 == 0 and ops.tall_ok(m, n, ks, True) and n > 128:
+        # the same GEMM tiling and the row-wise kernel's own arithmetic: bit for bit
+        assert torch.equal(y, y0) and torch.equal(yn, yn0), (float((y - y0).abs().max()), float((yn - yn0).abs().max()))
     torch.testing.assert_close(y, y0, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(yn, yn0, rtol=2e-5, atol=2e-6)
     assert yn.data_ptr() == slot.data_ptr()
@@ -1156,6 +1159,46 @@ def test_device_entry_points_reject_bad_arguments(L, ops, gpu_device):
 ])
 def test_module_matches_oracle_at_realistic_widths(L, O, gpu_device, agg, layers, dim, gate, scale, scoring):
     _module_against_oracle(L, O, gpu_device, agg, layers, dim, dim, gate, scale, scoring)
+
+
+@pytest.mark.parametrize("agg,layers,dim,gate", [("gcn", 2, 128, "mul"), ("graphsage", 2, 64, None), ("gcn", 1, 256, None)])
+def test_module_with_the_fused_layer_launch_matches_oracle_and_the_unfused_pair(L, O, ops, gpu_device, agg, layers, dim, gate):
+    """ops.FUSED_LAYER: an aggregation layer's Linear + LeakyReLU + LayerNorm (+ normalised copy) as ONE launch whose backward
+    recomputes z (on the listed rows under the loss's row-sparse gradients): against the oracle like every module test, and
+    against the same module on the unfused pair -- loss and the propagated table bit for bit, gradients to rounding."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    old = ops.FUSED_LAYER
+    try:
+        ops.FUSED_LAYER = True
+        _module_against_oracle(L, O, gpu_device, agg, layers, dim, dim, gate, None, "transr")
+        n, e = 20_000, 150_000
+        h, t, r = make_kg(n, e, seed=5)
+        cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=layers, aggregation_type=agg,
+                            use_num_lit=gate == "mul", use_txt_lit=gate == "mul", txt_lit_dim=300, device=gpu_device)
+        torch.manual_seed(3)
+        num = torch.rand(n, 2) if cfg.use_num_lit else None
+        txt = torch.randn(n, 300) if cfg.use_txt_lit else None
+        a_in = io.initial_a_in(n, h, t, r)
+        batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 200, 3, seed=9)]
+        got = {}
+        for fused in (True, False):
+            ops.FUSED_LAYER = fused
+            torch.manual_seed(11)
+            m = L.LiteralKG(cfg, n, 16, a_in, num, txt).to(gpu_device).eval()
+            loss = m(*batch, device=gpu_device, mode="pre_training")
+            loss.backward()
+            got[fused] = (float(loss), m.gat_embed.detach().clone(), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
+    finally:
+        ops.FUSED_LAYER = old
+    if dim > 128:      # the unfused Linear runs on the same 256-column tiling: bit for bit (narrower ones: another tile's rounding)
+        assert got[True][0] == got[False][0]
+        assert torch.equal(got[True][1], got[False][1])
+    assert abs(got[True][0] - got[False][0]) <= 1e-6 * abs(got[False][0])
+    torch.testing.assert_close(got[True][1], got[False][1], rtol=1e-5, atol=1e-6)
+    for k, g_f in got[True][2].items():
+        g_u = got[False][2][k]
+        assert float((g_f - g_u).abs().max()) <= 2e-5 * (float(g_u.abs().max()) + 1e-12), k
 
 
 def test_module_matches_oracle_at_the_reference_default_architecture(L, O, gpu_device):
