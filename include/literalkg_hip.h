@@ -527,6 +527,13 @@ int lkg_adam_step_f32(int64_t n, float *param, const float *grad, float *exp_avg
  * Used for nn.Linear forward (trans_b = 1), its data gradient and its weight
  * gradient (model.py:111 etc., gate.py:24-25, linear_gat model.py:309).          */
 int64_t lkg_gemm_workspace(int32_t trans_a, int64_t m, int64_t n, int64_t k);
+
+/* C[m,n] = opA(A)[m,k] opB(B)[k,n] with float64 accumulation, rounded to float32 once; SMALL products only (m n <= 2^24,
+ * m n k <= 2^34).  The GCNII-style residual's weight fold W_lin (W')^T of the device path (model.py:95-98 evaluates
+ * Linear(mixed @ W'); the device multiplies the two small matrices first and runs ONE N-row product): W' has near-equal
+ * entries, and an fp32 fold's accumulated rounding is what ill-conditioned residual configurations' scores then see.   */
+int lkg_gemm_f64acc_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float *a, int64_t lda,
+                        const float *b, int64_t ldb, float *c, int64_t ldc, void *stream);
 int lkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                  int64_t ldc, const float *bias, void *workspace, int64_t workspace_bytes, void *stream);

@@ -73,6 +73,7 @@ PROTOTYPES = {
                                          vp, vp, f32, u64, vp, i64, vp],
     "lkg_gemm_workspace": [i32, i64, i64, i64],
     "lkg_gemm_f32": [i32, i32, i64, i64, i64, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i64, vp],
+    "lkg_gemm_f64acc_f32": [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_colsum_f32": [i64, i32, vp, i64, vp, vp],
     "lkg_col_absmax_f32": [i64, i32, vp, i64, vp, vp],
     "lkg_gemm_longk_ok": [i64, i64, i64, vp, i64, vp, i64],

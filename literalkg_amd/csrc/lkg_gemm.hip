@@ -702,6 +702,43 @@ extern "C" int lkg_grouped_gemm_f32(int32_t mode, int32_t n_groups, const int32_
     return run(trans_a != 0, trans_b != 0, g, dim3((unsigned)tiles, (unsigned)n_groups), (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small products with float64 accumulation, rounded to float32 ONCE: C = op(A) op(B).  For the GCNII-style residual's weight
+// fold W_lin (W')^T (model.py:95-98: d x d x out, once per layer and step): W' = (1 - b) + b W has near-equal entries, so
+// the product is a large common part plus a small informative one, and the LayerNorm behind it removes the common part --
+// an fp32 dot product's accumulated rounding there is what the scores of ill-conditioned residual configurations see.
+// One thread per output element, 16 x 16 outputs per workgroup; a few MFLOP: the launch is its cost.
+namespace {
+__global__ __launch_bounds__(256) void gemm_f64acc_kernel(int ta, int tb, long m, long n, long k, const float *__restrict__ a,
+                                                          long lda, const float *__restrict__ b, long ldb,
+                                                          float *__restrict__ c, long ldc) {
+    const long i = (long)blockIdx.y * 16 + (threadIdx.x >> 4), j = (long)blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= m || j >= n) return;
+    double acc = 0.0;
+    for (long p = 0; p < k; ++p) {
+        const float av = ta ? a[p * lda + i] : a[i * lda + p];
+        const float bv = tb ? b[j * ldb + p] : b[p * ldb + j];
+        acc = fma((double)av, (double)bv, acc);
+    }
+    c[i * ldc + j] = (float)acc;
+}
+}  // namespace
+
+extern "C" int lkg_gemm_f64acc_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+                                   int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, void *stream) {
+    LKG_REQUIRE(m >= 0 && n >= 0 && k >= 0, "lkg_gemm_f64acc_f32: negative size");
+    if (m == 0 || n == 0) return LKG_OK;
+    LKG_REQUIRE(c && ldc >= n && (k == 0 || (a && b)), "lkg_gemm_f64acc_f32: null pointer / ldc smaller than n");
+    LKG_REQUIRE(k == 0 || (lda >= (trans_a ? m : k) && ldb >= (trans_b ? k : n)), "lkg_gemm_f64acc_f32: row strides smaller "
+                "than the stored rows");
+    LKG_REQUIRE(m * n <= (1L << 24) && m * n * k <= (1L << 34), "lkg_gemm_f64acc_f32: a helper for SMALL products (weight "
+                "folds); %lld x %lld x %lld belongs on lkg_gemm_f32", (long long)m, (long long)n, (long long)k);
+    hipLaunchKernelGGL(gemm_f64acc_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)((m + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, trans_a, trans_b, (long)m, (long)n, (long)k, a, (long)lda, b, (long)ldb, c, (long)ldc);
+    LKG_CHECK_LAUNCH("lkg_gemm_f64acc_f32");
+    return LKG_OK;
+}
+
 // lkg_preload(): HIP loads a translation unit's code object on the first use of one of its kernels; asking for a kernel's
 // attributes is such a use (no launch).
 int lkg_internal_preload_gemm() {

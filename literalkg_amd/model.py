@@ -101,6 +101,11 @@ class Aggregator(nn.Module):
                 self.linears = nn.ModuleList(nn.Linear(hid, hid) for _ in range(self.num_layers - 1))
                 self.out_linear = nn.Linear(hid, out_dim)
                 self.mlp_layer_norms = nn.ModuleList(nn.LayerNorm(hid) for _ in range(self.num_layers - 1))
+        # reference_association (args, default False): evaluate a residual layer as the reference writes it --
+        # Linear(mixed @ W') with W' = (1 - b) + b W (model.py:95-98), two N-row products -- instead of the device's fold
+        # mixed @ (W_lin W'^T)^T.  Same function; a parity run on an ill-conditioned residual configuration (W' has near-equal
+        # entries, LayerNorm removes their common part) then rounds where the reference rounds.
+        self.reference_association = bool(getattr(args, "reference_association", False))
         self.last_normalized = None
         self.h0_projection = None   # set by the encoder for the duration of a pass: linear_h0(h0) of this layer
         self.norm_out = None   # set by the encoder: the concat-buffer slice the normalised copy goes to
@@ -132,7 +137,11 @@ class Aggregator(nn.Module):
         first (d x d x out: nothing), the N-row product runs once, at the Linear's output width (for the 300-wide first layer
         of main.py's defaults: 1 M x 300 x 32 instead of 1 M x 300 x 300 and then 1 M x 300 x 32, forward and backward).
         Same value up to fp32 rounding order."""
-        return ops.linear(mixed, ops.matmul(mod.weight, wp.t()), mod.bias)
+        if self.reference_association:
+            return ops.linear(ops.matmul(mixed, wp), mod.weight, mod.bias)
+        # (the fold of the two small matrices in float64, rounded once: its fp32 dot products' accumulated rounding would be the
+        #  device path's own contribution to the error of an ill-conditioned configuration)
+        return ops.linear(mixed, ops.fold_nt(mod.weight, wp) if mixed.is_cuda else ops.matmul(mod.weight, wp.t()), mod.bias)
 
     def _res_lin(self, mod: nn.Linear, hi, h0, lamda, alpha, l):
         """mod(residual_connection(hi)), with the identity mapping folded into the Linear's weight on the device path."""

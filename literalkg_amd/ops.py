@@ -1098,6 +1098,45 @@ def matmul(a, b):
 
 
 # ----------------------------------------------------------------------------- small element-wise steps
+def gemm_f64acc(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False) -> torch.Tensor:
+    """op(a) @ op(b) with float64 accumulation, rounded to float32 once (lkg_gemm_f64acc_f32: small products only)."""
+    a, b = _f32_rows(a), _f32_rows(b)
+    _need_gpu(a, b)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    kb, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if k != kb:
+        raise ValueError(f"gemm_f64acc: inner dimensions {k} and {kb} differ")
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    N.call("lkg_gemm_f64acc_f32", int(trans_a), int(trans_b), m, n, k, N.ptr(a), _ld(a), N.ptr(b), _ld(b), N.ptr(out), _ld(out),
+           _stream())
+    return out
+
+
+class _FoldNT(Function):
+    """a @ b^T for two SMALL matrices, float64 accumulation (forward and both gradients): the residual's weight fold."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm_f64acc(a, b, trans_b=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = gemm_f64acc(g, b) if ctx.needs_input_grad[0] else None
+        gb = gemm_f64acc(g, a, trans_a=True) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+FOLD_F64 = _os.environ.get("LKG_FOLD_F32", "0") in ("", "0")      # (LKG_FOLD_F32=1: the fp32 fold of rounds 2-3, kept for
+#                                                                     before / after measurements of the residual sweeps)
+
+
+def fold_nt(a, b):
+    """a @ b^T, float64 accumulation (small matrices)"""
+    return _FoldNT.apply(a, b) if FOLD_F64 else matmul(a, b.t())
+
+
 def _elt(op, a, b=None, alpha=1.0, beta=0.0):
     a = _f32_rows(a)
     b = _f32_rows(b) if b is not None else None

@@ -122,8 +122,11 @@ def _sharded_from_fixture(g, scheme, sparse, kernels, scoring="transr", partitio
     state["A_in"] = torch.sparse_coo_tensor(torch.from_numpy(g["a_indices"]), torch.from_numpy(g["a_values"]), (n, n)).coalesce()
     num = torch.from_numpy(g["num"]) if "num" in g else None
     txt = torch.from_numpy(g["txt"]) if "txt" in g else None
+    # sparse "never-plain": the dense exchange WITHOUT the pipelined passes (pipelined=False: plain all-to-all, one SpMM,
+    # plain all-to-all back -- the form a first run on real links bisects against)
     return ShardedLiteralKG.from_full(cfg, n, n_rel, state, num, txt, scoring=scoring, scheme=scheme, device="cpu",
-                                      kernels=kernels, sparse_backward=sparse, partition=partition)
+                                      kernels=kernels, sparse_backward=sparse.split("-")[0], partition=partition,
+                                      pipelined=not sparse.endswith("-plain"))
 
 
 def _check_grads(m, g, prefix, world):
@@ -168,7 +171,7 @@ def _heads_worker(rank, world, port, scheme, sparse, q):
             assert _check_grads(m, g, "g/", world) >= 4
             t = dict(D.TRAFFIC)
             n_layers = int(golden_cfg(g).n_conv_layers)
-            if sparse == "always":           # every aggregation's backward went out as frontier rows, never as a table
+            if sparse.startswith("always"):  # every aggregation's backward went out as frontier rows, never as a table
                 assert t.get("aggregate_backward", 0) == 0 and t.get("frontier_rows", 0) > 0, t
                 widest = max(int(golden_cfg(g).embed_dim), int(golden_cfg(g).conv_dim))
                 n_msgs = t["frontier_ids"] // 8              # one int64 id per message row
@@ -218,7 +221,8 @@ def _heads_worker(rank, world, port, scheme, sparse, q):
 
 
 @pytest.mark.parametrize("world,scheme,sparse", [(2, "rows", "always"), (2, "rows", "never"), (2, "features", "always"),
-                                                  (2, "features", "never"), (4, "rows", "always"), (3, "features", "auto")])
+                                                  (2, "features", "never"), (4, "rows", "always"), (3, "features", "auto"),
+                                                  (2, "features", "never-plain"), (8, "features", "never")])
 def test_sharded_module_serves_every_mode(world, scheme, sparse):
     """pre_training / fine_tuning / predict / mlp of the row-sharded module against the reference's fixtures (losses,
     scores, every gradient), with the aggregation's backward as a frontier exchange and as the dense exchange, and the

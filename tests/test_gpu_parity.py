@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
 generated from the reference.  Tolerances: integer indices bit-exact; fp32 values within 1e-4
 (BASELINE.json north_star), most checks far tighter.  Run with ``-m gpu`` on the MI355X box."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -723,6 +725,27 @@ def _build_model(L, gd, device, scoring):
     return m.to(device).eval()
 
 
+# Gradients of the reference-generated fixtures: within GRAD_TOL of the parameter's LARGEST gradient entry -- 1e-4, the north
+# star's tolerance, for every parameter but the ones listed (measured on MI355X, LKG_GRAD_REPORT=1 prints every distance).
+GRAD_TOL = 1e-4
+GRAD_TOL_EXCEPTIONS = {}        # (fixture name or "*", parameter name substring) -> tolerance; filled from the measured run
+GRAD_REPORT = bool(os.environ.get("LKG_GRAD_REPORT"))
+
+
+def fixture_grad_close(got, want, name, key):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = float(np.abs(want).max()) + 1e-30
+    err = float(np.abs(got - want).max()) / scale
+    tol = GRAD_TOL
+    for (fx, sub), t in GRAD_TOL_EXCEPTIONS.items():
+        if (fx == "*" or fx == name) and sub in key:
+            tol = max(tol, t)
+    if GRAD_REPORT:
+        print(f"GRAD {name} {key} {err:.3e} largest {scale:.3e}")
+        return
+    assert err <= tol, (name, key, err, tol)
+
+
 @pytest.mark.parametrize("name", golden_names("encoder_") + golden_names("transe_"))
 def test_module_matches_reference_fixture(L, gpu_device, name):
     gd = load_golden(name)
@@ -740,7 +763,7 @@ def test_module_matches_reference_fixture(L, gpu_device, name):
     for k, want in gd.items():
         if k.startswith("g/"):
             assert k[2:] in grads, k
-            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+            fixture_grad_close(grads[k[2:]].cpu().numpy(), want, name, k[2:])
             n_checked += 1
     assert n_checked >= 4
     if form == "transr":
@@ -1201,6 +1224,60 @@ def test_module_with_the_fused_layer_launch_matches_oracle_and_the_unfused_pair(
         assert float((g_f - g_u).abs().max()) <= 2e-5 * (float(g_u.abs().max()) + 1e-12), k
 
 
+@pytest.mark.parametrize("shape", [(300, 300, 300), (32, 300, 300), (7, 5, 3), (256, 64, 256), (1, 1, 1)])
+def test_small_product_with_float64_accumulation(ops, gpu_device, shape):
+    """lkg_gemm_f64acc_f32 (the residual's weight fold): every layout against float64 on the host, rounded once"""
+    m, n, k = shape
+    gen = torch.Generator().manual_seed(m * 7 + n)
+    a, b = torch.randn(m, k, generator=gen), torch.randn(k, n, generator=gen)
+    want = (a.double() @ b.double()).float()
+    for ta, tb in ((False, False), (True, False), (False, True), (True, True)):
+        aa = (a.t().contiguous() if ta else a).to(gpu_device)
+        bb = (b.t().contiguous() if tb else b).to(gpu_device)
+        got = ops.gemm_f64acc(aa, bb, trans_a=ta, trans_b=tb).cpu()
+        ulp = torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)
+        assert bool(((got - want).abs() <= ulp).all()), (ta, tb, float((got - want).abs().max()))
+    x = a.to(gpu_device).requires_grad_(True)
+    y = b.t().contiguous().to(gpu_device).requires_grad_(True)
+    ops.fold_nt(x, y).square().sum().backward()
+    xr, yr = a.double().requires_grad_(True), b.t().double().requires_grad_(True)
+    (xr @ yr.t()).square().sum().backward()
+    torch.testing.assert_close(x.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-6 * float(xr.grad.abs().max()) + 1e-30)
+    torch.testing.assert_close(y.grad.cpu().double(), yr.grad, rtol=1e-5, atol=1e-6 * float(yr.grad.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("agg", ["gcn", "graphsage", "bi-interaction"])
+def test_residual_layers_in_the_reference_association(L, O, gpu_device, agg):
+    """args.reference_association: residual layers evaluated as the reference writes them (Linear(mixed @ W'), model.py:95-98)
+    instead of through the folded weight.  Both forms against the oracle in float64 -- the propagated table within 1e-4 of the
+    largest entry either way -- and the reference-association form at least as close to the fp32 oracle as the fold."""
+    from literalkg_amd.synth import make_kg
+    from literalkg_amd import io
+    n, dim = 20_000, 64
+    h, t, r = make_kg(n, 150_000, seed=5)
+    a_in = io.initial_a_in(n, h, t, r)
+    got = {}
+    for ref_assoc in (False, True):
+        cfg = O.default_cfg(embed_dim=dim, relation_dim=dim, conv_dim=dim, n_conv_layers=3, aggregation_type=agg,
+                            use_residual=True, mlp_hidden_dim=48, device=gpu_device, reference_association=ref_assoc)
+        torch.manual_seed(3)
+        m = L.LiteralKG(cfg, n, 16, a_in, None, None)
+        params = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "A_in"}
+        m.to(gpu_device).eval()
+        with torch.no_grad():
+            got[ref_assoc] = m.gat_embeddings().cpu()
+    want32 = O.gat_embeddings(params, cfg, a_in, None, None)
+    want64 = O.gat_embeddings({k: v.double() if v.is_floating_point() else v for k, v in params.items()}, cfg, a_in.double(), None, None)
+    scale = float(want64.abs().max())
+    e_fold = float((got[False].double() - want64).abs().max()) / scale
+    e_ref = float((got[True].double() - want64).abs().max()) / scale
+    e_o32 = float((want32.double() - want64).abs().max()) / scale
+    print(f"{agg}: vs float64 -- fold {e_fold:.2e}, reference association {e_ref:.2e}, fp32 oracle {e_o32:.2e}")
+    assert e_fold <= max(1e-4, 10 * e_o32) and e_ref <= max(1e-4, 10 * e_o32)
+    d_ref = float((got[True] - want32).abs().max()) / scale
+    assert d_ref <= max(1e-4, 10 * e_o32)
+
+
 def test_module_matches_oracle_at_the_reference_default_architecture(L, O, gpu_device):
     """argument_pretraining.py's defaults (lines 34-62): embed_dim = relation_dim = scale_gat_dim = 300, EIGHT gcn layers of
     conv_dim 32 (concatenated width 300 + 8 * 32 = 556 -> linear_gat -> 300), GateMul over 2 numeric + 300 text literals,
@@ -1483,7 +1560,7 @@ def test_pruned_step_matches_reference_fixture(L, gpu_device, name):
     for k, want in gd.items():
         if k.startswith("g/"):
             assert k[2:] in grads, k
-            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+            fixture_grad_close(grads[k[2:]].cpu().numpy(), want, name + " (pruned)", k[2:])
     if form == "transr":
         hid, tid = torch.from_numpy(gd["score_heads"]).to(gpu_device), torch.from_numpy(gd["score_tails"]).to(gpu_device)
         with torch.no_grad():
@@ -1809,7 +1886,7 @@ def test_mlp_head_matches_reference_fixture(L, gpu_device, name):
     for k, want in gd.items():
         if k.startswith("g/"):
             assert k[2:] in grads, k
-            np.testing.assert_allclose(grads[k[2:]].cpu().numpy(), want, rtol=2e-3, atol=2e-6, err_msg=k)
+            fixture_grad_close(grads[k[2:]].cpu().numpy(), want, "mlp head", k[2:])
     sd = m.state_dict()
     for k, want in gd.items():
         if k.startswith("after/"):                               # running statistics and the batch counter
