@@ -23,8 +23,13 @@ def _headers():
            [os.path.join(HERE, "..", "include", "literalkg_hip.h")]
 
 
-def _stale():
+TAG_FILE = os.path.join(HERE, "lib", "flags.tag")
+
+
+def _stale(tag):
     if not os.path.exists(LIB):
+        return True
+    if os.path.exists(TAG_FILE) and open(TAG_FILE).read().strip() != tag:     # linked from objects of other flags
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "literalkg_hip.h")]
@@ -36,14 +41,14 @@ def _flag_tag(extra):
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
+    extra = os.environ.get("LKG_EXTRA_HIPCC_FLAGS", "").split()      # kernel A/B experiments only
+    tag = _flag_tag(extra)
+    if not force and not _stale(tag):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build literalkg_amd/lib/liblkg_hip.so")
     os.makedirs(OBJ, exist_ok=True)
-    extra = os.environ.get("LKG_EXTRA_HIPCC_FLAGS", "").split()      # kernel A/B experiments only
-    tag = _flag_tag(extra)
     newest_header = max(os.path.getmtime(h) for h in _headers())
     todo, objs = [], []
     for s in SOURCES:
@@ -68,6 +73,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(TAG_FILE, "w") as f:
+        f.write(tag + "\n")
     return LIB
 
 

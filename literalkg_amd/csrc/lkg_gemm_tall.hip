@@ -583,6 +583,9 @@ void gemm_tall_kernel(TallArgs g) {
         }
     };
 
+#ifdef LKG_WS_STAMPS
+    unsigned long long t_e_math = 0, t_e_put = 0, t_e_flush = 0;
+#endif
     auto epilogue = [&](const long m0, const int n0) {
     // ---- epilogue (of the tile whose numbers are handed in: by then setup() may describe the next one).  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
         // holds ONE column of 16 rows.  Written as it stands that is 16 dword stores per tile (two 128-byte runs per
@@ -674,6 +677,7 @@ void gemm_tall_kernel(TallArgs g) {
                     if (col0 >= g.n) continue;                                // wave-uniform
                     const int lr0 = wm * 64 + i * 32 + 4 * (lane >> 5);       // row inside the tile
                     float out[16];
+                    LKG_STAMP(a0_);
     #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dr = (r & 3) + 8 * (r >> 2);
@@ -681,8 +685,15 @@ void gemm_tall_kernel(TallArgs g) {
                         if constexpr (!ONE) v = fmaf(cor[i][j][r], 1.f / 2048.f, v);
                         out[r] = g.alpha * ldexpf(v, -(ea_s[lr0 + dr] + eb_v[j])) + bias_v[j];
                     }
+#ifdef LKG_WS_STAMPS
+                    asm volatile("s_nop 0" :: "v"(out[15]), "v"(out[0]));
+#endif
+                    LKG_STAMP(a1_);
                     put(out);
+                    LKG_STAMP(a2_);
                     flush(g.c, g.ldc, m0 + wm * 64 + i * 32, col0, g.n, g.beta);
+                    LKG_STAMP(a3_);
+                    LKG_STAMP_ADD(t_e_math, a0_, a1_); LKG_STAMP_ADD(t_e_put, a1_, a2_); LKG_STAMP_ADD(t_e_flush, a2_, a3_);
                     __builtin_amdgcn_sched_barrier(0);     // one 32x32 tile at a time: short live ranges next to 128 accumulators
                 }
         } else if constexpr (EPI == EPI_ACTLN) {
@@ -874,7 +885,8 @@ void gemm_tall_kernel(TallArgs g) {
     // fragment reads + 12 MFMAs of tile t, with the split of tile t+1 (ring -> planes of the other buffer) in their
     // shadow.  Past the last tile the staged / fetched tiles are duplicates of the last one (in bounds, never read).
 #ifdef LKG_WS_STAMPS
-    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_step = 0, t_epi = 0, t_pro = 0, n_steps = 0;
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_step = 0, t_epi = 0, t_pro = 0, n_steps = 0, t_tail = 0, t_after = 0;
+    const unsigned long long all0_ = __builtin_amdgcn_s_memtime();
 #define LKG_WAIT_BARRIER(N)                                                                                  \
     do {                                                                                                     \
         LKG_STAMP(w0_);                                                                                      \
@@ -953,6 +965,7 @@ void gemm_tall_kernel(TallArgs g) {
             slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
             slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
         }
+        LKG_STAMP(q0_);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the duplicate tiles still in flight target the ring / buffers
 
         const long e_m0 = m0;                                  // (the epilogue's tile; tile_regs() moves on to the next one)
@@ -967,17 +980,23 @@ void gemm_tall_kernel(TallArgs g) {
             request_first(true);
         }
         LKG_STAMP(e0_);
+        LKG_STAMP_ADD(t_tail, q0_, e0_);
         epilogue(e_m0, e_n0);
         LKG_STAMP(e1_);
         LKG_STAMP_ADD(t_epi, e0_, e1_);
         if (!more) break;
         __syncthreads();     // the transposes are done with buffer 1's A planes and the tile's LDS scalars: the next tile moves in
+        LKG_STAMP(e2_);
+        LKG_STAMP_ADD(t_after, e1_, e2_);
     }
 #ifdef LKG_WS_STAMPS
     if (EPI == EPI_PLAIN && g.z_out && (threadIdx.x & 63) == 0) {
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.z_out);
         atomicAdd(dbg + 16, t_wait); atomicAdd(dbg + 17, t_bar); atomicAdd(dbg + 18, t_issue); atomicAdd(dbg + 19, t_step);
         atomicAdd(dbg + 20, t_epi); atomicAdd(dbg + 21, t_pro); atomicAdd(dbg + 22, n_steps);
+        atomicAdd(dbg + 23, t_e_math); atomicAdd(dbg + 24, t_e_put); atomicAdd(dbg + 25, t_e_flush);
+        atomicAdd(dbg + 26, t_tail); atomicAdd(dbg + 27, t_after); atomicAdd(dbg + 28, __builtin_amdgcn_s_memtime() - all0_);
+        atomicAdd(dbg + 29, 1ull);
     }
 #endif
 #undef LKG_WAIT_BARRIER
