@@ -60,6 +60,22 @@ enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_ACTLN = 2 };
 #define LKG_STAMP_ADD(acc, a, b)
 #endif
 
+// LDS reads of an EPILOGUE, hidden from the compiler.  hipcc cannot tell which LDS-DMA (global_load ... lds) wrote the bytes a
+// ds_read it can see may alias, so it puts `s_waitcnt vmcnt(0)` in front of every such read of the staging array -- and vmcnt
+// counts STORES too: in a loop "read 16 bytes back from the transpose, store them" every read then waits for the previous
+// store's round trip to memory (~1000 cycles each; measured with the stamps below: 16-20 k of a tile's 56 k cycles).  The
+// bytes these reads want were written by ds_write of the same wave (the LDS queue is in order per wave) or sit behind a
+// workgroup barrier; no DMA targets them while an epilogue runs (the next tile's first loads land beyond the transposes).
+typedef float lkg_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const void lkg_lds_cvoid;
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(unsigned long)(lkg_lds_cvoid *)p; }
+__device__ __forceinline__ void lds_read16_issue(lkg_f32x4 &v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+#define LKG_LDS_READS_DONE_4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+#define LKG_LDS_READS_DONE_3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) :: "memory")
+#define LKG_LDS_READS_DONE_2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) :: "memory")
+
 
 struct TallArgs {
     long m;
@@ -426,12 +442,22 @@ void gemm_tall_kernel(TallArgs g) {
     // (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') -- the compiler's own order puts the split behind the last
     // MFMA, where every instruction of it costs its full issue time.
 #define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
+    // The step's first fragments (hi planes) are requested right behind the barrier, in front of the step's DMA requests and
+    // together with the ring read-back: ONE wait for LDS per step instead of two in a row (ring, then fragments).
+    f16x8 a0[2], b0[2];
+    auto first_frags = [&](const _Float16 *S) {
+        if constexpr (!PRE) {
+            a0[0] = frag<BN>(S, wm * 64, lane);
+            b0[0] = frag<BN>(S + 2 * APL, wn * WN, lane);
+            b0[1] = frag<BN>(S + 2 * APL, wn * WN + 32, lane);
+            a0[1] = frag<BN>(S, wm * 64 + 32, lane);
+        }
+    };
     auto step = [&](const _Float16 *S, _Float16 *D, bool do_stage) {
-        // fragments are fetched where their registers become free (all eight up front would hold 32 registers at once)
-        f16x8 a0[2], b0[2], a1[2], b1[2];
+        // the other fragments are fetched where their registers become free (all eight up front would hold 32 registers at once)
+        f16x8 a1[2], b1[2];
         auto fa = [&](int i, int pl) { return frag<BN>(S + pl * APL, wm * 64 + i * 32, lane); };
         auto fb = [&](int j, int pl) { return frag<BN>(S + 2 * APL + pl * BPL, wn * WN + j * 32, lane); };
-        if constexpr (!PRE) { a0[0] = fa(0, 0); b0[0] = fb(0, 0); b0[1] = fb(1, 0); a0[1] = fa(1, 0); }
         const _Float16 sc = (_Float16)(1.f / 2048.f);
         f16x8 ahs[2], bhs[2];
         float e[EPT];
@@ -492,7 +518,11 @@ void gemm_tall_kernel(TallArgs g) {
                 *reinterpret_cast<fp16x4 *>(pa + APL + q) = mv;
             }
         };
+#ifdef LKG_ABL_NO_MFMA      /* (ablation builds, tools/tall_ablation.sh: what is the k loop waiting for?) */
+#define LKG_MFMA(C, A_, B_) asm volatile("" :: "v"(A_), "v"(B_))
+#else
 #define LKG_MFMA(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
+#endif
         LKG_PIN();
         if constexpr (PRE) {
             // 24 MFMAs: hi.hi, mid'.hi, hi.mid' over the wave's 2 x 4 blocks; a fragment is fetched where its registers
@@ -600,10 +630,15 @@ void gemm_tall_kernel(TallArgs g) {
         auto flush = [&](float *base, long ld, long row0, int col0, int n_cols, float beta) {
             const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
             const int col = col0 + 4 * (lane & 7);
+            lkg_f32x4 tv[4];
+            const unsigned ta = lds_addr_of(ts + (lane >> 3) * 32 + 4 * (lane & 7));
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) lds_read16_issue(tv[q], ta + q * 1024);
+            LKG_LDS_READS_DONE_4(tv[0], tv[1], tv[2], tv[3]);
     #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const long row = row0 + 8 * q + (lane >> 3);
-                float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+                float4 v = make_float4(tv[q][0], tv[q][1], tv[q][2], tv[q][3]);
                 if (row >= g.m) continue;
                 float *dst = base + row * ld + col;
                 if (vec && col + 3 < n_cols) {
@@ -618,6 +653,9 @@ void gemm_tall_kernel(TallArgs g) {
 #else
                     typedef float nt4 __attribute__((ext_vector_type(4)));
                     const nt4 nv = {v.x, v.y, v.z, v.w};
+#ifdef LKG_ABL_NO_STORE
+                    if (g.m < 0)
+#endif
                     __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(dst));
 #endif
                 } else {
@@ -639,10 +677,13 @@ void gemm_tall_kernel(TallArgs g) {
         auto flush_half = [&](float *base, long ld, long row0, int col0, int n_cols, int h) {
             const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
             const int col = col0 + 4 * (lane & 7);
+            const unsigned ta = lds_addr_of(ts + (16 * h + (lane >> 3)) * 32 + 4 * (lane & 7));
     #pragma unroll
             for (int q = 2 * h; q < 2 * h + 2; ++q) {
                 const long row = row0 + 8 * q + (lane >> 3);
-                const float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+                lkg_f32x4 tv;                              // (one at a time: the gate's epilogue has no 8 registers to spare)
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tv) : "v"(ta + (q - 2 * h) * 1024) : "memory");
+                const float4 v = make_float4(tv[0], tv[1], tv[2], tv[3]);
                 if (row >= g.m) continue;
                 float *dst = base + row * ld + col;
                 if (vec && col + 3 < n_cols) {
@@ -712,8 +753,14 @@ void gemm_tall_kernel(TallArgs g) {
             // The epilogue's own operands (19 dwords of kernel arguments) are read HERE, through an opaque pointer to the
             // kernel-argument segment: as fields of `g` they are loaded at kernel entry and sit in SGPRs through the k loop, the
             // scalar file overflows into VGPR lanes and the 128-VGPR budget with them (6 spilled VGPRs in the tile-opening code).
-            const TallArgs *L = (const TallArgs *)__builtin_amdgcn_kernarg_segment_ptr();      // (a cast across address spaces)
-            asm volatile("" : "+s"(L));
+            // They are read ONCE, here, with scalar loads (the pointer keeps its constant address space): as a generic pointer
+            // every use became a flat load + s_waitcnt vmcnt(0) in the row loop -- a wait for every store in flight.
+            typedef __attribute__((address_space(4))) const TallArgs KArgs;
+            KArgs *Lp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(Lp));
+            struct { float slope, ln_eps, norm_eps, drop_p; unsigned long long seed; const float *gamma, *beta_ln; float *yn; long ldyn; float *mean, *rstd; } Lv =
+                {Lp->slope, Lp->ln_eps, Lp->norm_eps, Lp->drop_p, Lp->seed, Lp->gamma, Lp->beta_ln, Lp->yn, Lp->ldyn, Lp->mean, Lp->rstd};
+            const auto *L = &Lv;
             constexpr int NWAVES = NT / 64, SROWS = 16, RPW = SROWS / NWAVES;  // rows of a slab per wave: 2 (8 waves)
             float *slab = reinterpret_cast<float *>(smem);                     // [16][BN], then gamma[BN], beta[BN]: 18 KB
             float *gb_s = slab + SROWS * BN;
@@ -748,10 +795,13 @@ void gemm_tall_kernel(TallArgs g) {
                 for (int rr = 0; rr < RPW; ++rr) {
                     const int row = wave * RPW + rr;                           // row of the slab
                     const long grow = m0 + sl * SROWS + row;
-                    const float4 z4 = *reinterpret_cast<const float4 *>(slab + row * BN + c4);
-                    const float4 gam4 = *reinterpret_cast<const float4 *>(gb_s + c4), bet4 = *reinterpret_cast<const float4 *>(gb_s + BN + c4);
-                    float a[4] = {z4.x, z4.y, z4.z, z4.w};
-                    const float gm[4] = {gam4.x, gam4.y, gam4.z, gam4.w}, bt[4] = {bet4.x, bet4.y, bet4.z, bet4.w};
+                    lkg_f32x4 z4, gam4, bet4;
+                    lds_read16_issue(z4, lds_addr_of(slab + row * BN + c4));
+                    lds_read16_issue(gam4, lds_addr_of(gb_s + c4));
+                    lds_read16_issue(bet4, lds_addr_of(gb_s + BN + c4));
+                    LKG_LDS_READS_DONE_3(z4, gam4, bet4);
+                    float a[4] = {z4[0], z4[1], z4[2], z4[3]};
+                    const float gm[4] = {gam4[0], gam4[1], gam4[2], gam4[3]}, bt[4] = {bet4[0], bet4[1], bet4[2], bet4[3]};
                     float s_ = 0.f;
     #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -784,7 +834,8 @@ void gemm_tall_kernel(TallArgs g) {
                         if (g.c) {
                             float *dst = g.c + grow * g.ldc + c4;
                             if (vec_y && c4 + 3 < g.n) {
-                                *reinterpret_cast<float4 *>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+                                const lkg_f32x4 o4 = {a[0], a[1], a[2], a[3]};
+                                __builtin_nontemporal_store(o4, reinterpret_cast<lkg_f32x4 *>(dst));
                             } else {
     #pragma unroll
                                 for (int k = 0; k < 4; ++k)
@@ -794,7 +845,8 @@ void gemm_tall_kernel(TallArgs g) {
                         if (L->yn) {
                             float *dst = L->yn + grow * L->ldyn + c4;
                             if (vec_n && c4 + 3 < g.n) {
-                                *reinterpret_cast<float4 *>(dst) = make_float4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+                                const lkg_f32x4 o4 = {a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv};
+                                __builtin_nontemporal_store(o4, reinterpret_cast<lkg_f32x4 *>(dst));
                             } else {
     #pragma unroll
                                 for (int k = 0; k < 4; ++k)
@@ -842,6 +894,9 @@ void gemm_tall_kernel(TallArgs g) {
                             const int r = 8 * h + q;
                             xv[q] = g.x[min(m0 + lr0 + (r & 3) + 8 * (r >> 2), g.m - 1) * g.ldx + cc];
                         }
+                        // The x loads are in flight while tanh / sigmoid are evaluated; x is first touched BEHIND that arithmetic: the
+                        // wait the compiler puts there is s_waitcnt vmcnt(0) (loads and stores share the counter and retire out of
+                        // order with each other), which also waits for the previous half's stores -- by then a half's arithmetic old.
                         float ov[8], gv[8], zv[8];
     #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -857,8 +912,10 @@ void gemm_tall_kernel(TallArgs g) {
                             const float zp = ldexpf(zs, -(e + ebz)) + bz;
                             gv[q] = tanh_fast(gp);
                             zv[q] = sigmoid_fast(zp);
-                            ov[q] = fmaf(zv[q], gv[q] - xv[q], xv[q]);        // (1 - z) x + z g
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int q = 0; q < 8; ++q) ov[q] = fmaf(zv[q], gv[q] - xv[q], xv[q]);   // (1 - z) x + z g
                         put_half(ov, h);
                         flush_half(g.c, g.ldc, row0, col0, d, h);
                         if (g.g_out) {
@@ -887,17 +944,23 @@ void gemm_tall_kernel(TallArgs g) {
 #ifdef LKG_WS_STAMPS
     unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_step = 0, t_epi = 0, t_pro = 0, n_steps = 0, t_tail = 0, t_after = 0;
     const unsigned long long all0_ = __builtin_amdgcn_s_memtime();
-#define LKG_WAIT_BARRIER(N)                                                                                  \
+#define LKG_WAIT_BARRIER(N, BETWEEN)                                                                         \
     do {                                                                                                     \
         LKG_STAMP(w0_);                                                                                      \
         asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");                                     \
         LKG_STAMP(w1_);                                                                                      \
+        BETWEEN;                                                                                             \
         asm volatile("s_barrier" ::: "memory");                                                              \
         LKG_STAMP(w2_);                                                                                      \
         LKG_STAMP_ADD(t_wait, w0_, w1_); LKG_STAMP_ADD(t_bar, w1_, w2_);                                     \
     } while (0)
 #else
-#define LKG_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define LKG_WAIT_BARRIER(N, BETWEEN)                                                                         \
+    do {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");                                     \
+        BETWEEN;                                                                                             \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+    } while (0)
 #endif
     // A tile's FIRST k step reads buffer 1: the epilogue's transposes use the first 32 KB of the staging LDS (buffer 0 and the A
     // planes of buffer 1), so the next tile's first B planes -- requested before that epilogue -- land beyond them.
@@ -948,14 +1011,22 @@ void gemm_tall_kernel(TallArgs g) {
             plan_a(2);
             plan_stage();
             _Float16 *cur = smem + ((gt + 1) & 1) * BUF, *nxt = smem + (gt & 1) * BUF;
-            if constexpr (NA == 1) LKG_WAIT_BARRIER(1); else LKG_WAIT_BARRIER(2);
+            // the ring read-back of tile gt + 1 (this thread's OWN pieces: landed once its vmcnt wait is over) is issued in front
+            // of the barrier: its LDS latency passes while the wave waits for the others
+            if constexpr (NA == 1) LKG_WAIT_BARRIER(1, ring_read(slot_s)); else LKG_WAIT_BARRIER(2, ring_read(slot_s));
             LKG_STAMP(k0_);
-            ring_read(slot_s);
+            first_frags(cur);
+#ifndef LKG_ABL_NO_DMA
             issue_b(gt + 1, nxt);
             issue_a(slot_f);
+#endif
             ring_wait();
             LKG_STAMP(k1_);
+#ifdef LKG_ABL_NO_STAGE
+            step(cur, nxt, false);
+#else
             step(cur, nxt, true);
+#endif
 #ifdef LKG_WS_STAMPS
             asm volatile("s_nop 0" :: "v"(acc[1][NJ - 1][0]));
             ++n_steps;
@@ -1297,10 +1368,15 @@ void gemm_tall_ws_kernel(TallArgs g) {
         const int lane = lane_e;
         const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
         const int col = col0 + 4 * (lane & 7);
+        lkg_f32x4 tv[4];
+        const unsigned ta = lds_addr_of(ts + (lane >> 3) * 32 + 4 * (lane & 7));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_read16_issue(tv[q], ta + q * 1024);
+        LKG_LDS_READS_DONE_4(tv[0], tv[1], tv[2], tv[3]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long row = row0 + 8 * q + (lane >> 3);
-            float4 v = *reinterpret_cast<const float4 *>(ts + (8 * q + (lane >> 3)) * 32 + 4 * (lane & 7));
+            float4 v = make_float4(tv[q][0], tv[q][1], tv[q][2], tv[q][3]);
             if (row >= g.m) continue;
             float *dst = base + row * ld + col;
             if (vec && col + 3 < n_cols) {

@@ -168,10 +168,10 @@ class Aggregator(nn.Module):
         return y
 
     def _linear_finish(self, xs, ws, bias):
-        """_finish(sum_i x_i @ w_i^T + bias): ONE launch when ops.FUSED_LAYER asks for it and the shape allows (whole rows in a
-        256-column tile), else the tall GEMM followed by the row-wise kernel (same bits either way)."""
-        if ops.FUSED_LAYER and xs[0].is_cuda and ops.fused_layer_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs]):
-            ln = self.layer_normalize
+        """_finish(sum_i x_i @ w_i^T + bias): ONE launch where ops.fused_layer_wanted says so (by default: evaluation, rows of
+        129-256 columns), else the tall GEMM followed by the row-wise kernel (same bits either way)."""
+        ln = self.layer_normalize
+        if ops.fused_layer_wanted(xs, ws, (bias, ln.weight, ln.bias)):
             p = float(self.dropout) if self.training else 0.0
             y, yn = ops.linear_act_layernorm(xs, ws, bias, ln.weight, ln.bias, want_norm=True, drop_p=p, yn_out=self.norm_out,
                                              want_y=self.want_output)

@@ -1361,12 +1361,27 @@ def act_layernorm(z, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS,
 
 
 # ----------------------------------------------------------------------------- K5 in one launch (opt-in)
-FUSED_LAYER = _os.environ.get("LKG_FUSED_LAYER", "0") not in ("", "0")
+def _fused_layer_mode():
+    v = _os.environ.get("LKG_FUSED_LAYER", "auto").strip().lower()
+    return {"": "auto", "auto": "auto", "0": False, "off": False, "1": True, "on": True}.get(v, "auto")
+
+
+FUSED_LAYER = _fused_layer_mode()
 """Route Linear + LeakyReLU + LayerNorm (+ dropout + normalised copy) of an aggregation layer through ONE launch
-(lkg_linear_act_layernorm_fwd_f32) where its shape allows.  OFF by default: measured on MI355X (profiles/r04_tall_variants_c.log,
-1 M x 256 x 256 with dropout) the fused launch takes 1.26 ms against 1.15 ms for the tall GEMM followed by the row-wise
-kernel -- the HBM pass it saves (z written and read back) costs less than the epilogue's 16 workgroup barriers per tile and
-the matrix pipe idling behind them.  Results are bit-identical either way."""
+(lkg_linear_act_layernorm_fwd_f32).  "auto" (the default): where it is the faster way -- rows wider than 128 columns (the
+launch's tile is 256 columns wide whatever the layer's width) and NO gradient to come, i.e. evaluation / link scoring:
+measured on MI355X (profiles/r04_tall_after_epilogue_fix.log, 1 M x 256 x 256) 1.04 ms against 1.14 ms for the tall GEMM
+followed by the row-wise kernel.  In training the pair stays: the backward pass needs z = x W^T + b, which the fused launch does not
+write, and recomputing it costs a second GEMM.  True: wherever the shape allows (tests); False: never.  Same bits every way."""
+
+
+def fused_layer_wanted(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor], others: Sequence[Optional[torch.Tensor]] = ()) -> bool:
+    if not FUSED_LAYER or not xs[0].is_cuda or not fused_layer_ok(xs[0].shape[0], ws[0].shape[0], [x.shape[1] for x in xs]):
+        return False
+    if FUSED_LAYER is True:
+        return True
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*xs, *ws, *others))
+    return ws[0].shape[0] > 128 and not needs_grad
 
 
 class _ShimCtx:

@@ -1184,6 +1184,26 @@ def test_module_matches_oracle_at_realistic_widths(L, O, gpu_device, agg, layers
     _module_against_oracle(L, O, gpu_device, agg, layers, dim, dim, gate, scale, scoring)
 
 
+def test_fused_layer_launch_is_chosen_for_evaluation_of_wide_layers_only(ops, gpu_device, monkeypatch):
+    """ops.FUSED_LAYER = "auto" (the default): the one-launch layer where it is the faster way -- no gradient to come and rows
+    of 129-256 columns; the GEMM + row-wise pair everywhere else (training needs z, which the fused launch does not write)."""
+    monkeypatch.setattr(ops, "FUSED_LAYER", "auto")
+    m = ops.TALL_MIN_ROWS
+    x = torch.randn(m, 256, device=gpu_device)
+    w = torch.nn.Parameter(torch.randn(256, 256, device=gpu_device))
+    w_narrow = torch.nn.Parameter(torch.randn(64, 256, device=gpu_device))
+    assert not ops.fused_layer_wanted((x,), (w,))
+    with torch.no_grad():
+        assert ops.fused_layer_wanted((x,), (w,))
+        assert not ops.fused_layer_wanted((x,), (w_narrow,))
+        assert not ops.fused_layer_wanted((x[:m // 2],), (w,))
+    assert ops.fused_layer_wanted((x,), (w.detach(),))
+    assert not ops.fused_layer_wanted((x,), (w.detach(),), (torch.nn.Parameter(torch.zeros(256, device=gpu_device)),))
+    monkeypatch.setattr(ops, "FUSED_LAYER", False)
+    with torch.no_grad():
+        assert not ops.fused_layer_wanted((x,), (w,))
+
+
 @pytest.mark.parametrize("agg,layers,dim,gate", [("gcn", 2, 128, "mul"), ("graphsage", 2, 64, None), ("gcn", 1, 256, None)])
 def test_module_with_the_fused_layer_launch_matches_oracle_and_the_unfused_pair(L, O, ops, gpu_device, agg, layers, dim, gate):
     """ops.FUSED_LAYER: an aggregation layer's Linear + LeakyReLU + LayerNorm (+ normalised copy) as ONE launch whose backward
