@@ -466,6 +466,25 @@ int lkg_gemm_longk_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t 
 int lkg_gemm_smallm_ok(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb);
 int lkg_gemm_smallm_f32(int64_t m, int64_t n, int64_t k, const float *a, int64_t lda, const float *b, int64_t ldb,
                         float *c, int64_t ldc, void *stream);
+
+/* The dense backward of a NARROW aggregation layer in one launch: y = Dropout(LayerNorm(LeakyReLU(x W^T + b))) with its
+ * L2-normalised copy yn, 32 columns in and out (the reference's default conv_dim: model.py:108-111, 161, 305 over
+ * argument_pretraining.py:54-58).  Replaces, for such a layer, lkg_act_layernorm_bwd_f32 + lkg_gemm_skinny_f32 (g_x = g_z W) +
+ * lkg_gemm_smallm_f32 (g_W = g_z^T x) + lkg_colsum_f32 (g_b): g_z stays in LDS, both products run as f32 MFMAs.
+ * x, z: the Linear's input and output rows as the forward pass kept them; y: required where g_yn is given; g_y and/or g_yn:
+ * the incoming gradients (either may be null); g_yn_rows: optional row flags of g_yn (0 = that row of g_yn is zero).
+ * Outputs: g_x [n, 32]; g_w [32 x 32, contiguous], g_bias (may be null), g_gamma, g_beta: OVERWRITTEN with the sums, which are
+ * added up in a fixed order (every workgroup's partial sums go through `workspace`, lkg_narrow_layer_bwd_workspace(n) floats).
+ * lkg_narrow_layer_bwd_ok: n >= 4096, d_in = d_out = 32, row strides multiples of 4 floats, 16-byte aligned operands. */
+int64_t lkg_narrow_layer_bwd_workspace(int64_t n);
+int lkg_narrow_layer_bwd_ok(int64_t n, int32_t d_in, int32_t d_out, const float *x, int64_t ldx, const float *z, int64_t ldz,
+                            const float *y, int64_t ldy, const float *g_y, int64_t ldgy, const float *g_yn, int64_t ldgyn);
+int lkg_narrow_layer_bwd_f32(int64_t n, int32_t d_in, int32_t d_out, const float *x, int64_t ldx, const float *w, int64_t ldw,
+                             const float *z, int64_t ldz, float slope, const float *gamma, const float *y, int64_t ldy,
+                             const float *save_mean, const float *save_rstd, const float *g_y, int64_t ldgy,
+                             const float *g_yn, int64_t ldgyn, float norm_eps, float drop_p, uint64_t seed,
+                             const uint8_t *g_yn_rows, float *g_x, int64_t ldgx, float *g_w, float *g_bias,
+                             float *g_gamma, float *g_beta, float *workspace, int64_t workspace_floats, void *stream);
 /* Skinny products over many rows: C[m, n] = A[m, k] . op(B) (+ bias) (+ beta C) for k, n <= 64 (op(B) = B[k, n], or
  * B[n, k]^T with trans_b: an nn.Linear weight) -- the 32 x 32 Linears, data gradients and residual mixes of narrow aggregation
  * layers (model.py:93-130 at the reference's default conv_dim 32).  Exact f32 FMAs on the VALU at streaming rate: op(B) stays

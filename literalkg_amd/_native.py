@@ -83,6 +83,10 @@ PROTOTYPES = {
     "lkg_gemm_skinny_f32": [i64, i64, i64, vp, i64, vp, i64, i32, f32, vp, i64, vp, vp],
     "lkg_gemm_smallm_f32": [i64, i64, i64, vp, i64, vp, i64, vp, i64, vp],
     "lkg_gemm_wgrad_f32": [i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp],
+    "lkg_narrow_layer_bwd_ok": [i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64],
+    "lkg_narrow_layer_bwd_workspace": [i64],
+    "lkg_narrow_layer_bwd_f32": [i64, i32, i32, vp, i64, vp, i64, vp, i64, f32, vp, vp, i64, vp, vp, vp, i64, vp, i64, f32, f32,
+                                 u64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp],
     "lkg_colsum_weighted_f32": [i64, i32, vp, i64, vp, i64, i32, vp, vp, i64, vp],
     "lkg_eltwise_f32": [i32, i64, i32, vp, i64, vp, i64, f32, f32, vp, i64, vp],
     "lkg_bi_mix_fwd_f32": [i64, i32, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, i64, vp],
@@ -91,7 +95,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"lkg_last_error": C.c_char_p, "lkg_csr_build_device_workspace": C.c_int64,
             "lkg_gemm_tall_workspace": C.c_int64, "lkg_gemm_workspace": C.c_int64,
-            "lkg_linear_act_layernorm_workspace": C.c_int64,
+            "lkg_linear_act_layernorm_workspace": C.c_int64, "lkg_narrow_layer_bwd_workspace": C.c_int64,
             "lkg_csr_transpose_device_workspace": C.c_int64}
 
 

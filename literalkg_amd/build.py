@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "liblkg_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["lkg_graph_host.cpp", "lkg_spmm.hip", "lkg_attention.hip", "lkg_score.hip", "lkg_rowwise.hip",
-           "lkg_gemm.hip", "lkg_batch.hip", "lkg_csr_device.hip", "lkg_gemm_tall.hip", "lkg_gemm_wgrad.hip"]
+           "lkg_gemm.hip", "lkg_batch.hip", "lkg_csr_device.hip", "lkg_gemm_tall.hip", "lkg_gemm_wgrad.hip", "lkg_layer.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 

@@ -43,9 +43,10 @@ int lkg_internal_preload_gemm_tall();
 int lkg_internal_preload_gemm_wgrad();
 int lkg_internal_preload_rowwise();
 int lkg_internal_preload_score();
+int lkg_internal_preload_layer();
 
 extern "C" int lkg_preload(void) {
-    const int failed = lkg_internal_preload_spmm() + lkg_internal_preload_attention() + lkg_internal_preload_batch() + lkg_internal_preload_csr_device() + lkg_internal_preload_gemm() + lkg_internal_preload_gemm_tall() + lkg_internal_preload_gemm_wgrad() + lkg_internal_preload_rowwise() + lkg_internal_preload_score();
+    const int failed = lkg_internal_preload_spmm() + lkg_internal_preload_attention() + lkg_internal_preload_batch() + lkg_internal_preload_csr_device() + lkg_internal_preload_gemm() + lkg_internal_preload_gemm_tall() + lkg_internal_preload_gemm_wgrad() + lkg_internal_preload_rowwise() + lkg_internal_preload_score() + lkg_internal_preload_layer();
     if (failed) {
         lkg_set_error("lkg_preload: %d of the library's code objects could not be loaded on the current device", failed);
         return LKG_ERR_HIP;

@@ -171,6 +171,12 @@ class Aggregator(nn.Module):
         """_finish(sum_i x_i @ w_i^T + bias): ONE launch where ops.fused_layer_wanted says so (by default: evaluation, rows of
         129-256 columns), else the tall GEMM followed by the row-wise kernel (same bits either way)."""
         ln = self.layer_normalize
+        if len(xs) == 1 and ops.narrow_layer_ok(xs[0], ws[0]):      # 32 -> 32: the dense backward in one launch
+            p = float(self.dropout) if self.training else 0.0
+            y, yn = ops.narrow_layer(xs[0], ws[0], bias, ln.weight, ln.bias, want_norm=True, drop_p=p, yn_out=self.norm_out,
+                                     want_y=self.want_output)
+            self.last_normalized = yn
+            return y
         if ops.fused_layer_wanted(xs, ws, (bias, ln.weight, ln.bias)):
             p = float(self.dropout) if self.training else 0.0
             y, yn = ops.linear_act_layernorm(xs, ws, bias, ln.weight, ln.bias, want_norm=True, drop_p=p, yn_out=self.norm_out,

@@ -1459,6 +1459,92 @@ def linear_act_layernorm(xs: Sequence[torch.Tensor], ws: Sequence[torch.Tensor],
                              yn_out, want_y, want_norm, *xs, *ws)
 
 
+# ----------------------------------------------------------------------------- a narrow layer's dense backward in one launch
+NARROW_LAYER = _os.environ.get("LKG_NARROW_LAYER", "1") not in ("", "0")
+"""Run the DENSE backward of a 32 -> 32 aggregation layer's Linear + LeakyReLU + LayerNorm (+ dropout + normalised copy) as one
+launch (lkg_narrow_layer_bwd_f32) instead of four (row-wise backward, data gradient, weight gradient, bias column sum).  The
+forward launches, and the backward under row-sparse gradients, are the unfused pair's own."""
+
+
+def narrow_layer_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (NARROW_LAYER and x.is_cuda and x.dim() == 2 and x.shape[1] == 32 and tuple(w.shape) == (32, 32) and x.shape[0] >= 4096
+            and _skinny(x, 32))
+
+
+class _NarrowLayer(Function):
+    """(y, yn) = Dropout(LayerNorm(LeakyReLU(x @ w^T + bias))) and its normalised copy (model.py:108-111, 161, 305) for the
+    reference's default conv_dim of 32.  Forward: the streaming f32 product and the row-wise kernel, as unfused.  Backward:
+    ONE launch when the incoming gradients are dense, else the unfused pair's own backward passes (row-sparse gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, want_norm, slope, eps, norm_eps, drop_p, seed, yn_out, want_y):
+        _need_gpu(x, w, gamma, beta)
+        x = _f32_rows(x)
+        z = gemm(x, w, trans_b=True, bias=bias)
+        n, d = z.shape
+        if not want_y and not want_norm:
+            raise ValueError("narrow_layer: neither output wanted")
+        y = torch.empty((n, d), dtype=torch.float32, device=z.device) if want_y else None
+        yn = None
+        if want_norm:
+            yn = yn_out if yn_out is not None else torch.empty((n, d), dtype=torch.float32, device=z.device)
+        mean = torch.empty(n, dtype=torch.float32, device=z.device)
+        rstd = torch.empty(n, dtype=torch.float32, device=z.device)
+        N.call("lkg_act_layernorm_fwd_f32", n, d, N.ptr(z), _ld(z), float(slope), N.ptr(gamma), N.ptr(beta),
+               float(eps), N.ptr(y), _ld(y) if y is not None else 0, N.ptr(yn), _ld(yn) if yn is not None else 0,
+               float(norm_eps), N.ptr(mean), N.ptr(rstd), float(drop_p), int(seed), _stream())
+        ctx.save_for_backward(x, w, z, gamma, beta, mean, rstd, *([y] if y is not None else []))
+        ctx.cfg = (slope, norm_eps, drop_p, seed)
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        return y, yn
+
+    @staticmethod
+    def backward(ctx, gy, gyn):
+        x, w, z, gamma, beta, mean, rstd, *kept_y = ctx.saved_tensors
+        y = kept_y[0] if kept_y else None
+        slope, norm_eps, drop_p, seed = ctx.cfg
+        none = (None,) * 13
+        if gy is None and gyn is None:
+            return none
+        n, d = z.shape
+        need = ctx.needs_input_grad
+        rows_n, rows_y = tagged_rows(gyn), tagged_rows(gy)
+        rows = union_rows(rows_y, rows_n) if (gy is None or rows_y is not None) and (gyn is None or rows_n is not None) else None
+        gy_ = _f32_rows(gy) if gy is not None else None
+        gyn_ = _f32_rows(gyn) if gyn is not None else None
+        fused = (not rows_worth_compacting(rows, n) and need[0] and need[1]
+                 and N.load().lkg_narrow_layer_bwd_ok(n, x.shape[1], d, N.ptr(x), _ld(x), N.ptr(z), _ld(z), N.ptr(y),
+                                                      _ld(y) if y is not None else 0, N.ptr(gy_), _ld(gy_) if gy_ is not None else 0,
+                                                      N.ptr(gyn_), _ld(gyn_) if gyn_ is not None else 0))
+        if not fused:       # the unfused pair's own backward passes (they carry the row sets on)
+            gz, gg, gb = _ActLayerNorm.backward(_ShimCtx((z, gamma, beta, mean, rstd, *kept_y), cfg=ctx.cfg), gy, gyn)[:3]
+            lin = _MultiLinear.backward(_ShimCtx((x, w), n_terms=1, has_bias=ctx.has_bias,
+                                                 needs_input_grad=(need[2], False, need[0], need[1])), gz)
+            return (lin[2], lin[3], lin[0], gg, gb) + none[5:]
+        gx = torch.empty((n, x.shape[1]), dtype=torch.float32, device=z.device)
+        sums = torch.empty(32 * 32 + 3 * 32, dtype=torch.float32, device=z.device)     # g_w | g_bias | g_gamma | g_beta
+        gw, gbias, gg, gb = sums[:1024].view(32, 32), sums[1024:1056], sums[1056:1088], sums[1088:1120]
+        wc = w if w.stride(1) == 1 else w.contiguous()
+        ws_floats = int(N.load().lkg_narrow_layer_bwd_workspace(n))
+        ws_ = _workspace(4 * ws_floats, z.device)
+        N.call("lkg_narrow_layer_bwd_f32", n, x.shape[1], d, N.ptr(x), _ld(x), N.ptr(wc), _ld(wc), N.ptr(z), _ld(z), float(slope),
+               N.ptr(gamma), N.ptr(y), _ld(y) if y is not None else 0, N.ptr(mean), N.ptr(rstd), N.ptr(gy_),
+               _ld(gy_) if gy_ is not None else 0, N.ptr(gyn_), _ld(gyn_) if gyn_ is not None else 0, float(norm_eps), float(drop_p),
+               int(seed), N.ptr(_flags(rows_n)) if gyn_ is not None else None, N.ptr(gx), _ld(gx), N.ptr(gw),
+               N.ptr(gbias) if (ctx.has_bias and need[2]) else None, N.ptr(gg), N.ptr(gb), N.ptr(ws_), ws_floats, _stream())
+        return (gx, gw, gbias if (ctx.has_bias and need[2]) else None, gg, gb) + none[5:]
+
+
+def narrow_layer(x, w, bias, gamma, beta, want_norm=True, slope=LEAKY_SLOPE, eps=LN_EPS, norm_eps=NORMALIZE_EPS,
+                 drop_p: float = 0.0, seed: Optional[int] = None, yn_out: Optional[torch.Tensor] = None, want_y: bool = True):
+    """(y, yn) of a 32 -> 32 aggregation layer's dense part; see _NarrowLayer / NARROW_LAYER."""
+    if drop_p > 0 and seed is None:
+        seed = new_seed()
+    return _NarrowLayer.apply(x, w, bias, gamma, beta, want_norm, float(slope), float(eps), float(norm_eps), float(drop_p),
+                              seed or 0, yn_out, want_y)
+
+
 # ----------------------------------------------------------------------------- concat without the copy
 class CatBuffer:
     """The N x (sum of widths) table that torch.cat(all_embed, dim=1) would build (model.py:309/314), allocated up

@@ -421,6 +421,74 @@ def test_fused_layer_epilogue_matches_the_unfused_pair(ops, gpu_device, m, ks, n
         torch.testing.assert_close(yn_only, yn, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("n", [4096 + 7, 50_000])
+@pytest.mark.parametrize("which", ["both", "y only", "yn only", "yn on some rows"])
+@pytest.mark.parametrize("drop_p", [0.0, 0.25])
+def test_narrow_layer_backward_in_one_launch_matches_the_unfused_passes(ops, gpu_device, n, which, drop_p):
+    """lkg_narrow_layer_bwd_f32 (a 32 -> 32 layer's row-wise backward, data gradient, weight gradient and bias sum in one launch,
+    g_z kept in LDS, the two products as f32 MFMAs) against the unfused passes on the same operands and the same dropout seed:
+    g_x, g_W, g_b, g_gamma, g_beta to summation-order rounding; and against float64 autograd of the same function."""
+    gen = torch.Generator().manual_seed(n + len(which))
+    x = (torch.randn(n, 32, generator=gen) * 0.7).to(gpu_device)
+    w = (torch.randn(32, 32, generator=gen) * 0.2).to(gpu_device)
+    bias = (torch.randn(32, generator=gen) * 0.1).to(gpu_device)
+    gamma = (1 + 0.1 * torch.randn(32, generator=gen)).to(gpu_device)
+    beta = (0.1 * torch.randn(32, generator=gen)).to(gpu_device)
+    gy = torch.randn(n, 32, generator=gen).to(gpu_device) if which in ("both", "y only") else None
+    gyn = torch.randn(n, 32, generator=gen).to(gpu_device) if which != "y only" else None
+    if which == "yn on some rows":                     # a loss's row-sparse gradient of the normalised copy, too many rows to compact
+        keep = (torch.rand(n, generator=gen) < 0.6).to(gpu_device)
+        gyn = gyn * keep[:, None]
+    seed = 99
+    got = {}
+    for fused in (True, False):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (x, w, bias, gamma, beta)]
+        xx, ww, bb, gg, be = leaves
+        if fused:
+            assert ops.narrow_layer_ok(xx, ww)
+            y, yn = ops.narrow_layer(xx, ww, bb, gg, be, drop_p=drop_p, seed=seed)
+        else:
+            y, yn = ops.act_layernorm(ops.linear(xx, ww, bb), gg, be, drop_p=drop_p, seed=seed)
+        torch.autograd.backward([t for t, g in ((y, gy), (yn, gyn)) if g is not None], [g for g in (gy, gyn) if g is not None])
+        got[fused] = (y.detach(), yn.detach(), [t.grad for t in leaves])
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    for name, a, b in zip(("g_x", "g_w", "g_bias", "g_gamma", "g_beta"), got[True][2], got[False][2]):
+        scale = float(b.abs().max()) + 1e-20
+        err = float((a - b).abs().max()) / scale
+        assert err < (2e-6 if name == "g_x" else 2e-5), (name, err)
+    if which == "yn on some rows":
+        # the row flags of g_yn (rows whose g_yn is zero are not read at all): the same sums as without them
+        from literalkg_amd import _native as N
+        z = ops.linear(x, w, bias)
+        y, mean, rstd = torch.empty_like(z), torch.empty(n, device=gpu_device), torch.empty(n, device=gpu_device)
+        N.call("lkg_act_layernorm_fwd_f32", n, 32, N.ptr(z), 32, 0.01, N.ptr(gamma), N.ptr(beta), 1e-5, N.ptr(y), 32, None, 0, 1e-12,
+               N.ptr(mean), N.ptr(rstd), float(drop_p), seed, None)
+        torch.cuda.synchronize()
+        outs = []
+        for flags in (None, keep.to(torch.uint8)):
+            gx = torch.empty_like(x)
+            sums = torch.empty(1024 + 96, device=gpu_device)
+            scratch = torch.empty(int(N.load().lkg_narrow_layer_bwd_workspace(n)), device=gpu_device)
+            garbage = gyn if flags is None else torch.where(keep[:, None], gyn, torch.full_like(gyn, float("nan")))
+            N.call("lkg_narrow_layer_bwd_f32", n, 32, 32, N.ptr(x), 32, N.ptr(w), 32, N.ptr(z), 32, 0.01, N.ptr(gamma), N.ptr(y), 32,
+                   N.ptr(mean), N.ptr(rstd), None, 0, N.ptr(garbage), 32, 1e-12, float(drop_p), seed, N.ptr(flags), N.ptr(gx), 32,
+                   N.ptr(sums[:1024]), N.ptr(sums[1024:1056]), N.ptr(sums[1056:1088]), N.ptr(sums[1088:]), N.ptr(scratch),
+                   scratch.numel(), None)
+            torch.cuda.synchronize()
+            outs.append((gx, sums))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # (the sums are added in a fixed order)
+    if drop_p == 0.0:
+        l64 = [t.detach().double().cpu().requires_grad_(True) for t in (x, w, bias, gamma, beta)]
+        z64 = l64[0] @ l64[1].t() + l64[2]
+        y64 = torch.nn.functional.layer_norm(torch.nn.functional.leaky_relu(z64, 0.01), (32,), l64[3], l64[4], 1e-5)
+        yn64 = y64 / y64.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        torch.autograd.backward([t for t, g in ((y64, gy), (yn64, gyn)) if g is not None],
+                                [g.double().cpu() for g in (gy, gyn) if g is not None])
+        for name, a, b in zip(("g_x", "g_w", "g_bias", "g_gamma", "g_beta"), got[True][2], l64):
+            err = float((a.double().cpu() - b.grad).abs().max()) / (float(b.grad.abs().max()) + 1e-20)
+            assert err < 1e-4, (name, err)
+
+
 def test_fused_gate_matches_oracle_and_the_unfused_path(L, ops, O, gpu_device):
     """GateMul / Gate through the one-launch stacked GEMM with the blend epilogue (rows >= 16384) against the oracle's
     gate (forward, input gradient, every weight gradient), with literal widths that are not multiples of 4."""
