@@ -453,6 +453,7 @@ void gemm_tall_kernel(TallArgs g) {
             a0[1] = frag<BN>(S, wm * 64 + 32, lane);
         }
     };
+    // (the step's DMA requests were also tried INSIDE the MFMA block, behind its first two MFMAs: no measurable difference)
     auto step = [&](const _Float16 *S, _Float16 *D, bool do_stage) {
         // the other fragments are fetched where their registers become free (all eight up front would hold 32 registers at once)
         f16x8 a1[2], b1[2];
@@ -524,6 +525,13 @@ void gemm_tall_kernel(TallArgs g) {
 #define LKG_MFMA(C, A_, B_) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C, 0, 0, 0)
 #endif
         LKG_PIN();
+        // The wave's MFMA block runs at a raised priority: of the four waves on a SIMD (two per workgroup) the one that has its
+        // fragments issues its MFMAs ahead of the others' address arithmetic and requests -- 2-3 % on every shape, measured in
+        // both orders in one process (1 M x 300 x 300 1.255 -> 1.214 ms, gate 2.366 -> 2.327 ms).
+#ifndef LKG_TALL_STEP_PRIO
+#define LKG_TALL_STEP_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(LKG_TALL_STEP_PRIO);
         if constexpr (PRE) {
             // 24 MFMAs: hi.hi, mid'.hi, hi.mid' over the wave's 2 x 4 blocks; a fragment is fetched where its registers
             // come free (peak: a hi 8 + b hi 16 + a mid' 8 + two b mid' 8), the split of the next tile rides behind them
@@ -582,6 +590,7 @@ void gemm_tall_kernel(TallArgs g) {
             LKG_MFMA(cor[1][0], a1[1], b0[0]); if (do_stage) p_write(); LKG_PIN();
             LKG_MFMA(cor[1][1], a1[1], b0[1]);
         }
+        __builtin_amdgcn_s_setprio(0);
 #undef LKG_MFMA
     };
 #undef LKG_PIN
