@@ -442,8 +442,8 @@ void gemm_tall_kernel(TallArgs g) {
     // (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') -- the compiler's own order puts the split behind the last
     // MFMA, where every instruction of it costs its full issue time.
 #define LKG_PIN() __builtin_amdgcn_sched_barrier(0)
-    // The step's first fragments (hi planes) are requested right behind the barrier, in front of the step's DMA requests and
-    // together with the ring read-back: ONE wait for LDS per step instead of two in a row (ring, then fragments).
+    // The step's first fragments (hi planes) are requested together with the ring read-back: ONE wait for LDS per step instead of
+    // two in a row (ring, then fragments).
     f16x8 a0[2], b0[2];
     auto first_frags = [&](const _Float16 *S) {
         if constexpr (!PRE) {
@@ -1024,11 +1024,11 @@ void gemm_tall_kernel(TallArgs g) {
             // of the barrier: its LDS latency passes while the wave waits for the others
             if constexpr (NA == 1) LKG_WAIT_BARRIER(1, ring_read(slot_s)); else LKG_WAIT_BARRIER(2, ring_read(slot_s));
             LKG_STAMP(k0_);
-            first_frags(cur);
 #ifndef LKG_ABL_NO_DMA
             issue_b(gt + 1, nxt);
             issue_a(slot_f);
 #endif
+            first_frags(cur);                      // (in front of the requests: no faster, and a register more)
             ring_wait();
             LKG_STAMP(k1_);
 #ifdef LKG_ABL_NO_STAGE
