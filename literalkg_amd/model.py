@@ -15,6 +15,7 @@ Differences in *structure* (results are the reference's):
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -322,6 +323,8 @@ class LiteralKG(nn.Module):
         self.prune_max_fraction = 0.5     # frontier larger than this share of the entities: the dense path is cheaper
         self.gat_rows = None
         self.group_reuse = True           # TransR: project (h, t+) once per group of pre_training_neg_rate rows
+        # linear_gat on the rows the loss reads instead of all N (calc_triplet_loss); LKG_ROWS_ONLY_PROJECTION=0: as the reference
+        self.project_batch_rows_only = os.environ.get("LKG_ROWS_ONLY_PROJECTION", "1") not in ("", "0")
         self.group_reuse_min_rate = 2     # ... from this many negatives per positive on (the layout check is the step's one
                                           #     host sync; measured at K = 3, B = 2049: the reuse still wins 0.3-0.5 ms)
         self._att: Optional[AttentionCSR] = None
@@ -373,11 +376,12 @@ class LiteralKG(nn.Module):
     def gate_embeddings(self):
         return self._gate(self.entity_embed.weight, *self._literals())
 
-    def gat_embeddings(self, defer_slot0: bool = False):
+    def gat_embeddings(self, defer_slot0: bool = False, project: bool = True):
         """The concatenated table (model.py:298-314).  defer_slot0 (no gate, no linear_gat): the copy of the raw entity
         table into column slot 0 is NOT made -- returns (table with slot 0 pending, raw table); a reader of <= 3B rows
         (the TransR loss) takes those columns from the raw table, anybody else goes through the ``gat_embed`` property,
-        which completes the table first."""
+        which completes the table first.  project = False: linear_gat + its activation (model.py:309-310) are NOT applied --
+        the caller applies them to the rows it reads (calc_triplet_loss)."""
         att = self._attention()
         # every producer writes its column slice of the concatenated table directly (no torch.cat pass)
         cb = ops.CatBuffer(self.n_entities, self.conv_dim_list, self.entity_embed.weight.device)
@@ -423,7 +427,7 @@ class LiteralKG(nn.Module):
                 cat = ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
             return cat, (self.entity_embed.weight if defer else None)
         cat = ops.assemble_cat(cb, kept)
-        if self.scale_gat_dim is not None:
+        if self.scale_gat_dim is not None and project:
             return ops.leaky_relu(ops.linear(cat, self.linear_gat.weight, self.linear_gat.bias))
         return cat
 
@@ -517,6 +521,22 @@ class LiteralKG(nn.Module):
         keep = self.last_scores if not self.training else None
         if self.training or torch.is_grad_enabled():
             self._eval_cache = None           # a training step is under way: the inference heads' kept table goes
+        if self.scoring == "transr" and self._rows_only_projection_applies():
+            # The loss reads <= 3B rows of linear_gat's output and a row of it depends on the same row of the concatenated table
+            # only: the projection (model.py:309-310) runs on those rows -- 1 M x 556 -> 300 was 2.5 of the reference-default
+            # step's 10.6 forward ms -- and the N-row table the reference leaves in self.gat_embed (model.py:380) is projected
+            # only if somebody reads that attribute.  Same loss, same gradients (the projection's backward already ran on
+            # these rows only).
+            cat = self._unprojected_table()         # (the encoder is queued before the layout check is waited for)
+            group = k if (check is not None and check.result()) else 1
+            n_g = h.numel() // group
+            rows, _ = self._projected_rows(cat, torch.cat([h[::group], pos_t[::group]]), neg_t)
+            of_group = torch.arange(n_g, device=h.device).repeat_interleave(group)
+            return ops.transr_loss(rows, self.relation_embed.weight, self.gat_trans_M, of_group, r, of_group + n_g,
+                                   2 * n_g + torch.arange(h.numel(), device=h.device), self.kg_l2loss_lambda, keep, group, False)
+        if self._rows_only_projection_applies():          # TransE on the same footing
+            rows, (h, pos_t, neg_t) = self._projected_rows(self._unprojected_table(), h, pos_t, neg_t)
+            return ops.transe_loss(rows, self.relation_embed.weight, h, r, pos_t, neg_t, self.kg_l2loss_lambda, keep, False)
         if self.scoring == "transr" and not self._can_prune():
             # the loss reads <= 3B rows: the N-row copy of the raw entity table into slot 0 of the concatenated table is
             # deferred (made only if somebody asks for self.gat_embed), its columns are read from the raw table
@@ -537,6 +557,32 @@ class LiteralKG(nn.Module):
         return ops.transe_loss(self.gat_embed, self.relation_embed.weight, h, r, pos_t, neg_t,
                                self.kg_l2loss_lambda, keep, sparse)
 
+    def _rows_only_projection_applies(self) -> bool:
+        """A loss that reads a few rows of linear_gat's output and has to run the encoder anyway (a training step, or any call
+        with autograd on: the inference heads' kept table is for eval mode under no_grad)."""
+        return (self.project_batch_rows_only and self.scale_gat_dim is not None and not self._can_prune()
+                and (self.training or torch.is_grad_enabled() or self.scoring == "transr"))
+
+    def _unprojected_table(self):
+        """The concatenated table without linear_gat; it stays behind self.gat_embed, projected on first access."""
+        self.gat_rows = None
+        cat = self.gat_embeddings(project=False)
+        self._gat_state = (cat, None, True)
+        self._raise_bad_ids()
+        return cat
+
+    def _projected_rows(self, cat, *id_lists):
+        """(linear_gat + activation of cat's rows id_lists[0] | id_lists[1] | ..., the lists relabelled to positions in it)"""
+        lists = [i.reshape(-1) for i in id_lists]
+        first, rest = lists[0], (torch.cat(lists[1:]) if len(lists) > 2 else lists[1])
+        a, b = ops.gather_rows_pair(cat, first, rest, self._table_grad_stays_inside())
+        rows = ops.leaky_relu(ops.linear(torch.cat([a, b]), self.linear_gat.weight, self.linear_gat.bias))
+        relabelled, at = [], 0
+        for i in lists:
+            relabelled.append(at + torch.arange(i.numel(), device=i.device))
+            at += i.numel()
+        return rows, tuple(relabelled)
+
     @staticmethod
     def _raise_bad_ids():
         """The ids a caller handed in were sanitised on the device at the start of the call (ops.checked_ids).  By now the
@@ -549,7 +595,11 @@ class LiteralKG(nn.Module):
     def gat_embed(self):
         """The table of the last encoder pass (the reference keeps it as an attribute, model.py:366).  A slot-0 copy that
         the loss deferred is made here, on first access."""
-        table, raw = self.__dict__.get("_gat_state", (None, None))
+        table, raw, *pending = self.__dict__.get("_gat_state", (None, None))
+        if table is not None and pending and pending[0]:       # linear_gat was applied to the batch's rows only: all rows now
+            with torch.no_grad():
+                table = ops.leaky_relu(ops.linear(table.detach(), self.linear_gat.weight, self.linear_gat.bias))
+            self._gat_state = (table, None)
         if table is not None and raw is not None:
             ops.fill_slot(table, 0, raw)
             self._gat_state = (table, None)
@@ -668,6 +718,10 @@ class LiteralKG(nn.Module):
     def calculate_prediction_loss(self, head_ids, tail_pos_ids, tail_neg_ids):
         """f1: dot-product BPR fine-tuning loss (model.py:316-348)."""
         head_ids, tail_pos_ids, tail_neg_ids = ops.checked_ids(self.id_space, head_ids, tail_pos_ids, tail_neg_ids)
+        if self._rows_only_projection_applies() and (self.training or torch.is_grad_enabled()):
+            rows, (head_ids, tail_pos_ids, tail_neg_ids) = self._projected_rows(self._unprojected_table(), head_ids, tail_pos_ids,
+                                                                                  tail_neg_ids)
+            return ops.dot_loss(rows, head_ids, tail_pos_ids, tail_neg_ids, self.prediction_l2loss_lambda, False)
         self.gat_embed, (head_ids, tail_pos_ids, tail_neg_ids) = self._embeddings_and_ids(
             head_ids, tail_pos_ids, tail_neg_ids)
         self._raise_bad_ids()

@@ -1272,6 +1272,42 @@ def test_fused_layer_launch_is_chosen_for_evaluation_of_wide_layers_only(ops, gp
         assert not ops.fused_layer_wanted((x,), (w,))
 
 
+@pytest.mark.parametrize("agg,layers,group", [("gcn", 3, True), ("bi-interaction", 2, False)])
+def test_projection_on_the_batch_rows_equals_the_projection_of_the_whole_table(L, O, gpu_device, agg, layers, group):
+    """calc_triplet_loss applies linear_gat + its activation (model.py:309-310) to the <= 3B rows the TransR loss reads instead
+    of all N (project_batch_rows_only): the same loss, the same gradients and -- read afterwards -- the same self.gat_embed as
+    with the whole table projected first, which is what the reference does (model.py:380)."""
+    from literalkg_amd.synth import make_batch, make_kg
+    from literalkg_amd import io
+    n, e = 20_000, 150_000
+    h, t, r = make_kg(n, e, seed=5)
+    cfg = O.default_cfg(embed_dim=48, relation_dim=40, conv_dim=32, n_conv_layers=layers, aggregation_type=agg, scale_gat_dim=56,
+                        use_num_lit=True, use_txt_lit=False, device=gpu_device)
+    torch.manual_seed(3)
+    num = torch.rand(n, 2)
+    a_in = io.initial_a_in(n, h, t, r)
+    batch = [torch.from_numpy(x).to(gpu_device) for x in make_batch(n, 200, 3, seed=9)]
+    if not group:          # no (h, r, t+) groups: every triple on its own
+        perm = torch.randperm(batch[0].numel(), generator=torch.Generator().manual_seed(1)).to(gpu_device)
+        batch = [b[perm] for b in batch]
+    got = {}
+    for rows_only in (True, False):
+        torch.manual_seed(11)
+        m = L.LiteralKG(cfg, n, 16, a_in, num, None).to(gpu_device).eval()
+        m.project_batch_rows_only = rows_only
+        loss = m(*batch, device=gpu_device, mode="pre_training")
+        loss.backward()
+        got[rows_only] = (float(loss), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None},
+                          m.gat_embed.detach().clone())
+        assert tuple(got[rows_only][2].shape) == (n, 56)
+    assert abs(got[True][0] - got[False][0]) <= 2e-6 * abs(got[False][0])
+    torch.testing.assert_close(got[True][2], got[False][2], rtol=1e-5, atol=1e-6)
+    assert got[True][1].keys() == got[False][1].keys()
+    for k, g in got[False][1].items():
+        err = float((got[True][1][k] - g).abs().max()) / (float(g.abs().max()) + 1e-30)
+        assert err < 2e-5, (k, err)
+
+
 @pytest.mark.parametrize("agg,layers,dim,gate", [("gcn", 2, 128, "mul"), ("graphsage", 2, 64, None), ("gcn", 1, 256, None)])
 def test_module_with_the_fused_layer_launch_matches_oracle_and_the_unfused_pair(L, O, ops, gpu_device, agg, layers, dim, gate):
     """ops.FUSED_LAYER: an aggregation layer's Linear + LeakyReLU + LayerNorm (+ normalised copy) as ONE launch whose backward
