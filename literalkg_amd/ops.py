@@ -1974,12 +1974,23 @@ class _TransRLoss(Function):
         # g_X = G W_r^T for the three row blocks in one grouped launch, scattered back to the table rows below
         _grouped(1, seg_all, max(b, n_g), gp, trans_m, gx, 0, c, dout, False, True, 0.0, stride_b=c * dout, b_period=n_rel)
         parts = ((hg, perm, seg, 0, n_g), (pg, perm, seg, n_g, n_g), (nt, perm_n, seg_n, 2 * n_g, b))
+        # g_W[r] = X_h^T G_h + X_+^T G_+ + X_-^T G_- over relation r's rows.  The three terms nearly cancel when the table's rows
+        # share a large common part v (G_h = -(G_+ + sum G_-) up to the regulariser): the reference adds them PER SAMPLE before it
+        # sums over the batch (model.py:391-397 under autograd); block after block they are rounded relative to the uncancelled
+        # partial sums -- 60 x the fp32 reference's own error with one relation and 683 groups (tests/test_gpu_fuzz.py, seed 44053).
+        # So the common part is taken out first:  g_W[r] = sum_i (x_i - v)^T g_i  +  v^T (sum_i g_i),  v = the mean row, and the second
+        # sum is taken per GROUP first (head + positive + its negatives: what is left of their cancellation), then over the groups.
+        v = x.mean(0, keepdim=True)
+        xc = x - v
         for i, (ids, pm, sg, off, rows) in enumerate(parts):
-            xi, gi = x[off:off + rows], gp[off:off + rows]
-            # g_W[r] (+)= X_r^T G_r
-            _grouped(2, sg, rows, xi, gi, g_w, c, dout, 0, True, False, 0.0 if i == 0 else 1.0, stride_c=c * dout)
+            # g_W[r] (+)= (X_r - v)^T G_r
+            _grouped(2, sg, rows, xc[off:off + rows], gp[off:off + rows], g_w, c, dout, 0, True, False, 0.0 if i == 0 else 1.0,
+                     stride_c=c * dout)
             N.call("lkg_scatter_add_rows_f32", rows, c, N.ptr(gx[off:]), c, N.ptr(ids), N.ptr(pm), N.ptr(g_emb),
                    _ld(g_emb), _stream())
+        per_group = gp[:n_g] + gp[n_g:2 * n_g] + gp[2 * n_g:].view(n_g, k, dout).sum(1)         # (rows are in relation order: rs)
+        per_rel = torch.zeros((n_rel, dout), dtype=torch.float32, device=dev).index_add_(0, rs, per_group)
+        g_w.addcmul_(v.view(1, c, 1), per_rel.view(n_rel, 1, dout))
         return g_emb, g_rel, g_w, None, None, None, None, None, None, None, None, None
 
 

@@ -1272,6 +1272,41 @@ def test_fused_layer_launch_is_chosen_for_evaluation_of_wide_layers_only(ops, gp
         assert not ops.fused_layer_wanted((x,), (w,))
 
 
+@pytest.mark.parametrize("n_rel,c,dout,k", [(1, 64, 8, 3), (4, 64, 8, 3), (1, 64, 8, 1), (16, 300, 300, 3)])
+def test_transr_matrix_gradient_keeps_the_reference_order_conditioning(ops, gpu_device, n_rel, c, dout, k):
+    """gat_trans_M's gradient sums x_h^T g_h + x_+^T g_+ + x_-^T g_- over the batch, and g_h = -(g_+ + sum g_-) up to the
+    regulariser: when the table's rows share a large common part the three blocks nearly cancel.  The reference adds them per
+    sample first (autograd over model.py:391-397), so its fp32 result stays accurate; block after block it was 60 x worse than
+    that (fuzz seed 44053: one relation, 683 groups).  The common part is taken out before the products: as accurate as the
+    reference's order (fp32 autograd on the CPU) against float64."""
+    torch.manual_seed(c + n_rel)
+    n, n_g = 9000, 683
+    emb = (torch.randn(n, c) * 0.01 + torch.randn(1, c)).to(gpu_device).requires_grad_(True)       # rows = common part + 1 %
+    rel = (torch.randn(n_rel, dout) * 0.1).to(gpu_device).requires_grad_(True)
+    M = (torch.randn(n_rel, c, dout) * 0.1).to(gpu_device).requires_grad_(True)
+    hg, rg, pg = torch.randint(0, n, (n_g,)), torch.randint(0, n_rel, (n_g,)), torch.randint(0, n, (n_g,))
+    h, r, pt = (t.repeat_interleave(k) for t in (hg, rg, pg))
+    nt = torch.randint(0, n, (n_g * k,))
+    ops.transr_loss(emb, rel, M, h.to(gpu_device), r.to(gpu_device), pt.to(gpu_device), nt.to(gpu_device), 1e-5, None, k, False).backward()
+
+    def grads(dtype):
+        e, rr, mm = (t.detach().to(dtype).cpu().requires_grad_(True) for t in (emb, rel, M))
+        w = mm[r]
+        a, b_, c_ = (torch.bmm(e[i].unsqueeze(1), w).squeeze(1) for i in (h, pt, nt))
+        d = rr[r]
+        l2 = lambda x: (x ** 2).sum(1).mean() / 2
+        loss = (-torch.nn.functional.logsigmoid(((a + d - c_) ** 2).sum(1) - ((a + d - b_) ** 2).sum(1))).mean() \
+            + 1e-5 * (l2(a) + l2(d) + l2(b_) + l2(c_))
+        loss.backward()
+        return mm.grad, e.grad, rr.grad
+    want, ref32 = grads(torch.float64), grads(torch.float32)
+    for name, got, w64, r32 in zip(("gat_trans_M", "table", "relation_embed"), (M.grad, emb.grad, rel.grad), want, ref32):
+        scale = float(w64.abs().max())
+        mine = float((got.double().cpu() - w64).abs().max()) / scale
+        theirs = float((r32.double() - w64).abs().max()) / scale
+        assert mine <= max(4 * theirs, 2e-6), (name, mine, theirs)
+
+
 @pytest.mark.parametrize("agg,layers,group", [("gcn", 3, True), ("bi-interaction", 2, False)])
 def test_projection_on_the_batch_rows_equals_the_projection_of_the_whole_table(L, O, gpu_device, agg, layers, group):
     """calc_triplet_loss applies linear_gat + its activation (model.py:309-310) to the <= 3B rows the TransR loss reads instead
