@@ -952,7 +952,11 @@ void gemm_tall_kernel(TallArgs g) {
     // shadow.  Past the last tile the staged / fetched tiles are duplicates of the last one (in bounds, never read).
 #ifdef LKG_WS_STAMPS
     unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_step = 0, t_epi = 0, t_pro = 0, n_steps = 0, t_tail = 0, t_after = 0;
-    const unsigned long long all0_ = __builtin_amdgcn_s_memtime();
+#endif
+#if defined(LKG_WS_STAMPS) || defined(LKG_CLOCK_STAMP)
+    const unsigned long long all0_ = __builtin_amdgcn_s_memtime(), real0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef LKG_WS_STAMPS
 #define LKG_WAIT_BARRIER(N, BETWEEN)                                                                         \
     do {                                                                                                     \
         LKG_STAMP(w0_);                                                                                      \
@@ -1077,6 +1081,14 @@ void gemm_tall_kernel(TallArgs g) {
         atomicAdd(dbg + 23, t_e_math); atomicAdd(dbg + 24, t_e_put); atomicAdd(dbg + 25, t_e_flush);
         atomicAdd(dbg + 26, t_tail); atomicAdd(dbg + 27, t_after); atomicAdd(dbg + 28, __builtin_amdgcn_s_memtime() - all0_);
         atomicAdd(dbg + 29, 1ull);
+        atomicAdd(dbg + 30, __builtin_amdgcn_s_memrealtime() - real0_);        // 100 MHz: the in-kernel clock = cycles / this * 100 MHz
+    }
+#elif defined(LKG_CLOCK_STAMP)      /* (the ONLY stamps of this build: two at kernel entry, two at its end -- MI355X_MICROARCH.md 'DVFS give-back' item 6) */
+    if (EPI == EPI_PLAIN && g.z_out && (threadIdx.x & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.z_out);
+        atomicAdd(dbg + 28, __builtin_amdgcn_s_memtime() - all0_);
+        atomicAdd(dbg + 29, 1ull);
+        atomicAdd(dbg + 30, __builtin_amdgcn_s_memrealtime() - real0_);
     }
 #endif
 #undef LKG_WAIT_BARRIER

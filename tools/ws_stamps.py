@@ -49,4 +49,5 @@ for k in (64, 256, 558):
               f"MFMAs + split {v[19] / ns:7.0f} | per tile: epilogue {v[20] / ns * kt:8.0f}  tile opening {v[21] / ns * kt:8.0f}"
               f" | of the epilogue: scale + bias {v[23] / ns * kt:7.0f}  LDS writes {v[24] / ns * kt:7.0f}  LDS reads + stores {v[25] / ns * kt:7.0f}"
               f" | k loop end -> epilogue {v[26] / ns * kt:7.0f}  barrier behind the epilogue {v[27] / ns * kt:7.0f}"
-              f" | whole kernel per wave {v[28] / max(v[29], 1):9.0f} cycles, stamped {sum(v[16:22]) / max(v[29], 1) + (v[26] + v[27]) / max(v[29], 1):9.0f}; launch {ms:.3f} ms (with the planes pass)")
+              f" | whole kernel per wave {v[28] / max(v[29], 1):9.0f} cycles, stamped {sum(v[16:22]) / max(v[29], 1) + (v[26] + v[27]) / max(v[29], 1):9.0f}; launch {ms:.3f} ms (with the planes pass)"
+              f" | in-kernel clock {v[28] / max(v[30], 1) * 0.1:.2f} GHz (s_memtime / s_memrealtime)")
