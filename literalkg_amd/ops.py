@@ -1513,7 +1513,7 @@ class _NarrowLayer(Function):
         rows = union_rows(rows_y, rows_n) if (gy is None or rows_y is not None) and (gyn is None or rows_n is not None) else None
         gy_ = _f32_rows(gy) if gy is not None else None
         gyn_ = _f32_rows(gyn) if gyn is not None else None
-        fused = (not rows_worth_compacting(rows, n) and need[0] and need[1]
+        fused = (not rows_worth_compacting(rows, n) and need[0] and need[1] and gamma.data_ptr() % 16 == 0
                  and N.load().lkg_narrow_layer_bwd_ok(n, x.shape[1], d, N.ptr(x), _ld(x), N.ptr(z), _ld(z), N.ptr(y),
                                                       _ld(y) if y is not None else 0, N.ptr(gy_), _ld(gy_) if gy_ is not None else 0,
                                                       N.ptr(gyn_), _ld(gyn_) if gyn_ is not None else 0))
@@ -1980,7 +1980,7 @@ class _TransRLoss(Function):
         # partial sums -- 60 x the fp32 reference's own error with one relation and 683 groups (tests/test_gpu_fuzz.py, seed 44053).
         # So the common part is taken out first:  g_W[r] = sum_i (x_i - v)^T g_i  +  v^T (sum_i g_i),  v = the mean row, and the second
         # sum is taken per GROUP first (head + positive + its negatives: what is left of their cancellation), then over the groups.
-        v = x.mean(0, keepdim=True)
+        v = x.mean(0, keepdim=True) if x.shape[0] else torch.zeros((1, c), dtype=torch.float32, device=dev)
         xc = x - v
         for i, (ids, pm, sg, off, rows) in enumerate(parts):
             # g_W[r] (+)= (X_r - v)^T G_r
