@@ -514,7 +514,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int tiles = g.tiles_m * g.tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
@@ -525,6 +524,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long k_lo = (long)split * per, k_hi = min(g.k, k_lo + per);
     if (k_lo >= k_hi) return;
     const int count = (int)((k_hi - k_lo) / RK);
+    // A tile at the edge of C whose real rows / columns fill at most half of it (600 x 300 in 256 x 128 tiles: 88 of 256, 44 of 128):
+    // the waves whose 64 x 64 block is all padding run no MFMAs.  The 4 x 2 wave grid is laid out so that the live waves sit one
+    // per SIMD (waves 0..3): by rows (wm = wave >> 1) when the rows are short, by columns (wn = wave >> 2) when the columns are.
+    const int m_live = (int)min(4l, (g.m - m0 + 63) / 64), n_live = (int)min(2l, (g.n - n0 + 63) / 64);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool by_cols = n_live == 1;
+    const int wm = by_cols ? (wave & 3) : (wave >> 1), wn = by_cols ? (wave >> 2) : (wave & 1);
+    const bool wave_live = (by_cols ? (wave_u & 3) : (wave_u >> 1)) < m_live && (by_cols ? (wave_u >> 2) : (wave_u & 1)) < n_live;
 
     const int ka = t >> 6, ca = 4 * (t & 63), kb = t >> 5, cb = 4 * (t & 31);
     const int keep_a = (m0 + ca + 3 < g.m) ? -1 : 0, keep_b = (n0 + cb + 3 < g.n) ? -1 : 0;
@@ -589,7 +596,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // the 12 MFMAs of the tile in S with the split of the next tile (register set r -> D) and the 2^-11 copies of the hi
     // fragments sliced between them
-    auto step = [&](const _Float16 *S, _Float16 *D, f32x4 (&r)[3], int live) {
+    auto step = [&](const _Float16 *S, _Float16 *D, f32x4 (&r)[3], int live, auto LIVE) {
+        if constexpr (!decltype(LIVE)::value) {       // a wave of padding: its share of the split, nothing else
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { t1(r, q, live); t2(q); }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) write_piece(p, D);
+            fetch(r);
+            return;
+        }
         const _Float16 *SA = S, *SB = S + 2 * RA_PLANE;
         f16x8 ah[2], am[2], bh[2], bm[2], ahs[2], bhs[2];
 #pragma unroll
@@ -627,14 +642,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int p = 0; p < 3; ++p) write_piece(p, planes);
     fetch(rs0);
     auto P = [&](int j) { return planes + (j & 1) * HBUF; };
-    for (int it = 0; it < count; it += 3) {
-        __syncthreads();
-        step(P(it), P(it + 1), rs1, it + 1 < count ? -1 : 0);
-        __syncthreads();
-        step(P(it + 1), P(it + 2), rs2, it + 2 < count ? -1 : 0);
-        __syncthreads();
-        step(P(it + 2), P(it + 3), rs0, it + 3 < count ? -1 : 0);
-    }
+    auto k_loop = [&](auto LIVE) {                     // (the whole loop twice: no branch between the accumulators' uses)
+        for (int it = 0; it < count; it += 3) {
+            __syncthreads();
+            step(P(it), P(it + 1), rs1, it + 1 < count ? -1 : 0, LIVE);
+            __syncthreads();
+            step(P(it + 1), P(it + 2), rs2, it + 2 < count ? -1 : 0, LIVE);
+            __syncthreads();
+            step(P(it + 2), P(it + 3), rs0, it + 3 < count ? -1 : 0, LIVE);
+        }
+    };
+    if (wave_live) k_loop(std::true_type{});
+    else { k_loop(std::false_type{}); return; }        // (nothing to store)
 
     const bool atomic_out = g.k_splits > 1;
 #pragma unroll
