@@ -264,12 +264,34 @@ void gemm_tall_kernel(TallArgs g) {
     if (slot >= xcd_count) return;                           // (workgroup-uniform)
 
     int arow = t / TPR, akc = t % TPR;                       // this thread's row / k chunk of the A tile
+    // A LAST column tile with real columns in at most half of its BN (300 = 256 + 44; the gate's 600 = 2 x 256 + 88): the waves whose
+    // columns are all padding run no MFMAs, and the 2 x 4 wave grid is laid out the other way round for that tile (wn = wave >> 1:
+    // the live waves are waves 0..3 or 0..1, one per SIMD) -- the tile's matrix work halves instead of idling two SIMDs.  The k loop
+    // exists twice (live / padding): a branch between the accumulators' uses inside it costs 12-170 spilled VGPRs.
+    constexpr bool SKIPS = (BN / WN == 4 && TM == 128 && EPI == EPI_PLAIN && ONE);     // (the gate's and the fused layer's kernels have no register to spare)
+    int alt = 0;                           // (of the tile in the k loop / its epilogue; workgroup-uniform)
+    bool act = true;                       // (wave-uniform)
     auto rethread = [&]() {
         int t_o = threadIdx.x;
         asm volatile("" : "+v"(t_o));
-        t = t_o; lane = t & 63; wave = t >> 6;
-        wm = wave / (BN / WN); wn = wave % (BN / WN);
+        t = t_o; lane = t & 63;
+        if constexpr (SKIPS) wave = __builtin_amdgcn_readfirstlane(t >> 6);        // (a scalar: so are wm, wn and what hangs on them)
+        else wave = t >> 6;
+        if (SKIPS && alt) {
+            wm = wave & 1; wn = wave >> 1;
+        } else {
+            wm = wave / (BN / WN); wn = wave % (BN / WN);
+        }
         arow = t / TPR; akc = t % TPR;
+    };
+    auto remap = [&](int n0_tile) {        // the wave grid of the tile that starts now
+        if constexpr (SKIPS) {
+            const int n_act = min(BN / WN, (g.n - n0_tile + WN - 1) / WN);
+            alt = n_act <= 2 ? 1 : 0;
+            const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            act = (alt ? (wave_u >> 1) : (wave_u % (BN / WN))) < n_act;
+            rethread();
+        }
     };
     // ---- per-tile state (set by setup(): the tile being computed, or -- from just before its epilogue on -- the next one)
     long m0 = 0, grow = 0;
@@ -985,6 +1007,7 @@ void gemm_tall_kernel(TallArgs g) {
         plan_a(2); if (issue) issue_a(2);
     };
     tile_regs(slot);
+    remap(n0);
     tile_prefetch();
     request_first(true);
     bool first_tile = true;
@@ -993,6 +1016,7 @@ void gemm_tall_kernel(TallArgs g) {
         if (!first_tile) {                         // (workgroup-uniform) re-derive what the epilogue was not asked to carry
             rethread();
             tile_regs(slot);
+            remap(n0);
             request_first(false);
         }
 #pragma unroll
@@ -1019,36 +1043,54 @@ void gemm_tall_kernel(TallArgs g) {
         stage_only(smem + BUF);
         LKG_STAMP(p1_);
         LKG_STAMP_ADD(t_pro, p0_, p1_);
-        int slot_f = 0, slot_s = 1;                // ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged
-        for (int gt = 0; gt < n_tiles; ++gt) {
-            plan_a(2);
-            plan_stage();
-            _Float16 *cur = smem + ((gt + 1) & 1) * BUF, *nxt = smem + (gt & 1) * BUF;
-            // the ring read-back of tile gt + 1 (this thread's OWN pieces: landed once its vmcnt wait is over) is issued in front
-            // of the barrier: its LDS latency passes while the wave waits for the others
-            if constexpr (NA == 1) LKG_WAIT_BARRIER(1, ring_read(slot_s)); else LKG_WAIT_BARRIER(2, ring_read(slot_s));
-            LKG_STAMP(k0_);
-#ifndef LKG_ABL_NO_DMA
-            issue_b(gt + 1, nxt);
-            issue_a(slot_f);
-#endif
-            first_frags(cur);                      // (in front of the requests: no faster, and a register more)
-            ring_wait();
-            LKG_STAMP(k1_);
-#ifdef LKG_ABL_NO_STAGE
-            step(cur, nxt, false);
+        // (the k loop as a macro: a wave of padding columns -- LIVE = false -- runs its share of the split and nothing else; written
+        //  out twice for the kernels that skip, and exactly as before for the others -- wrapped in a lambda it cost the gate's
+        //  kernel 11 spilled VGPRs)
+#ifdef LKG_ABL_NO_DMA
+#define LKG_LOOP_ISSUE()
 #else
-            step(cur, nxt, true);
+#define LKG_LOOP_ISSUE() do { issue_b(gt + 1, nxt); issue_a(slot_f); } while (0)
+#endif
+#ifdef LKG_ABL_NO_STAGE
+#define LKG_LOOP_STEP(LIVE) step(cur, nxt, false)
+#else
+#define LKG_LOOP_STEP(LIVE) do { if constexpr (LIVE) step(cur, nxt, true); else stage_only(nxt); } while (0)
 #endif
 #ifdef LKG_WS_STAMPS
-            asm volatile("s_nop 0" :: "v"(acc[1][NJ - 1][0]));
-            ++n_steps;
+#define LKG_LOOP_COUNT() do { asm volatile("s_nop 0" :: "v"(acc[1][NJ - 1][0])); ++n_steps; } while (0)
+#else
+#define LKG_LOOP_COUNT()
 #endif
-            LKG_STAMP(k2_);
-            LKG_STAMP_ADD(t_issue, k0_, k1_); LKG_STAMP_ADD(t_step, k1_, k2_);
-            slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;
-            slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;
+#define LKG_K_LOOP(LIVE)                                                                                                  \
+        {                                                                                                                 \
+            int slot_f = 0, slot_s = 1;      /* ring slots: tile gt + 3 goes where tile gt was; tile gt + 1 is staged */  \
+            for (int gt = 0; gt < n_tiles; ++gt) {                                                                        \
+                plan_a(2);                                                                                                \
+                plan_stage();                                                                                             \
+                _Float16 *cur = smem + ((gt + 1) & 1) * BUF, *nxt = smem + (gt & 1) * BUF;                                \
+                /* the ring read-back of tile gt + 1 (this thread's OWN pieces: landed once its vmcnt wait is over) is    \
+                   issued in front of the barrier: its LDS latency passes while the wave waits for the others */          \
+                if constexpr (NA == 1) LKG_WAIT_BARRIER(1, ring_read(slot_s)); else LKG_WAIT_BARRIER(2, ring_read(slot_s)); \
+                LKG_STAMP(k0_);                                                                                           \
+                LKG_LOOP_ISSUE();                                                                                         \
+                if constexpr (LIVE) first_frags(cur);   /* (in front of the requests: no faster, and a register more) */  \
+                ring_wait();                                                                                              \
+                LKG_STAMP(k1_);                                                                                           \
+                LKG_LOOP_STEP(LIVE);                                                                                      \
+                LKG_LOOP_COUNT();                                                                                         \
+                LKG_STAMP(k2_);                                                                                           \
+                LKG_STAMP_ADD(t_issue, k0_, k1_); LKG_STAMP_ADD(t_step, k1_, k2_);                                        \
+                slot_f = slot_f == RING - 1 ? 0 : slot_f + 1;                                                             \
+                slot_s = slot_s == RING - 1 ? 0 : slot_s + 1;                                                             \
+            }                                                                                                             \
         }
+        if constexpr (SKIPS) {
+            if (act) LKG_K_LOOP(true) else LKG_K_LOOP(false)
+        } else LKG_K_LOOP(true)
+#undef LKG_K_LOOP
+#undef LKG_LOOP_COUNT
+#undef LKG_LOOP_STEP
+#undef LKG_LOOP_ISSUE
         LKG_STAMP(q0_);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the duplicate tiles still in flight target the ring / buffers
 
