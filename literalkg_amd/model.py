@@ -433,15 +433,20 @@ class LiteralKG(nn.Module):
 
     def _can_prune(self) -> bool:
         # gin sums earlier layers' outputs row by row (model.py:151-158): not wired for compact rows
-        return self.prune_to_batch and self.aggregation_type != "gin"
+        # (a frontier that outgrew prune_max_fraction -- deep models: the reference's eight layers reach everything from 2 049
+        # triples -- is not tried again for PRUNE_RETRY_EVERY calls of forward(): an attempt costs two levels of index bookkeeping)
+        return self.prune_to_batch and self.aggregation_type != "gin" and self.__dict__.get("_prune_skip", 0) == 0
+
+    PRUNE_RETRY_EVERY = 64
 
     def gat_embeddings_for(self, ids: torch.Tensor):
         """Rows `unique(ids)` of gat_embeddings(), computed on the batch's L-hop frontier only (pruned.py).
         Returns (compact table, BatchSubgraph), or (None, None) when the frontier covers more than
         ``prune_max_fraction`` of the entities (large batches x many layers: the dense path is cheaper then)."""
         att = self._attention()
-        sub = pruned.build_batch_subgraph(att.graph, att.val, ids, self.n_layers)
-        if sub.rows[0].numel() > self.prune_max_fraction * self.n_entities:
+        sub = pruned.build_batch_subgraph(att.graph, att.val, ids, self.n_layers,
+                                          max_rows=int(self.prune_max_fraction * self.n_entities))
+        if sub is None:
             return None, None
         top = self.n_layers
         num, txt = self._literals()
@@ -505,6 +510,7 @@ class LiteralKG(nn.Module):
         table, sub = self.gat_embeddings_for(torch.cat([i.reshape(-1) for i in id_lists]))
         if table is None:
             self.gat_rows = None
+            self._prune_skip = self.PRUNE_RETRY_EVERY
             return self.gat_embeddings(), id_lists
         self.gat_rows = sub.rows[-1]
         return table, tuple(sub.positions(i) for i in id_lists)
@@ -709,6 +715,8 @@ class LiteralKG(nn.Module):
 
     def forward(self, *input, device, mode):
         self.device = device
+        if self.__dict__.get("_prune_skip", 0) > 0 and mode != "update_att":
+            self._prune_skip -= 1
         if mode in ("pre_training", "fine_tuning", "mlp") and (self.training or torch.is_grad_enabled()):
             self._eval_cache = None           # a training step: whatever table the inference heads kept is about to be stale
         if mode == "pre_training":

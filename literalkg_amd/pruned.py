@@ -50,7 +50,10 @@ class BatchSubgraph:
 
 
 @torch.no_grad()
-def build_batch_subgraph(graph: KGStructure, val: torch.Tensor, ids: torch.Tensor, n_layers: int) -> BatchSubgraph:
+def build_batch_subgraph(graph: KGStructure, val: torch.Tensor, ids: torch.Tensor, n_layers: int,
+                         max_rows: Optional[int] = None) -> Optional[BatchSubgraph]:
+    """max_rows: give up (None) as soon as a level's row set outgrows it -- the caller takes the dense path, and a deep model
+    does not pay for eight levels of bookkeeping to find that out (the reference's default architecture: two levels instead)."""
     ops._need_gpu(ids, val)
     rows = [None] * (n_layers + 1)
     layers: List[Optional[SubLayer]] = [None] * (n_layers + 1)
@@ -69,6 +72,8 @@ def build_batch_subgraph(graph: KGStructure, val: torch.Tensor, ids: torch.Tenso
                    N.ptr(out_rowptr), N.ptr(out_col), N.ptr(out_val), ops._stream())
         col_ids = out_col[:m].long()
         prev = torch.unique(torch.cat([rk, col_ids]))
+        if max_rows is not None and prev.numel() > max_rows:
+            return None
         rows[k - 1] = prev
         layers[k] = SubLayer(out_rowptr, torch.searchsorted(prev, col_ids).int(), out_val[:m], rk.numel(),
                              prev.numel(), torch.searchsorted(prev, rk))

@@ -1732,6 +1732,31 @@ def test_pruned_step_matches_reference_fixture(L, gpu_device, name):
                                    rtol=2e-3, atol=2e-6)
 
 
+def test_pruned_step_backs_off_when_the_frontier_covers_the_graph(L, gpu_device):
+    """prune_to_batch on a model whose frontier outgrows prune_max_fraction (here: the fixture graph with the fraction set to a
+    few rows): the step falls back to the dense path with the dense path's results, and the next PRUNE_RETRY_EVERY - 1 calls
+    of forward() do not pay for another attempt; then pruning is tried again."""
+    gd = load_golden("encoder_gcn_l2_gatenum")
+    m = _build_model(L, gd, gpu_device, "transr")
+    batch = [torch.from_numpy(gd[k]).to(gpu_device) for k in ("bh", "br", "bp", "bn")]
+    m.prune_to_batch = True
+    m.prune_max_fraction = 1e-3                    # nothing fits: every attempt gives up at its first level
+    m.PRUNE_RETRY_EVERY = 3
+    loss = m(*batch, device=gpu_device, mode="pre_training")
+    np.testing.assert_allclose(float(loss.detach()), float(gd["loss"]), rtol=1e-5)
+    assert m.gat_rows is None and m._prune_skip == 3 and not m._can_prune()
+    for left in (2, 1):
+        again = m(*batch, device=gpu_device, mode="pre_training")
+        assert m._prune_skip == left and float(again.detach()) == pytest.approx(float(loss.detach()), rel=1e-6)
+    m(*batch, device=gpu_device, mode="pre_training")     # the back-off is over: this call tries again (and backs off again)
+    assert m._prune_skip == 3
+    m.prune_max_fraction = 1.0                     # ... and prunes when the frontier fits
+    m._prune_skip = 0
+    pruned_loss = m(*batch, device=gpu_device, mode="pre_training")
+    assert m.gat_rows is not None
+    np.testing.assert_allclose(float(pruned_loss.detach()), float(gd["loss"]), rtol=1e-5)
+
+
 def test_pruned_trajectory_matches_reference(L, gpu_device):
     gd = load_golden("trajectory_gcn_l2_gatemul_scale")
     m = _build_model(L, gd, gpu_device, "transr")
